@@ -1,0 +1,1090 @@
+// libazamd engine: G lockstep Go games and their PUCT search trees resident in HBM, one wavefront
+// per game (or per pending leaf) for every kernel. See include/azamd.h for the C ABI.
+//
+// Search semantics follow go_zero/mcts.py line by line in float64: PUCT score and first-strict-max
+// tie-break (mcts.py:97-116), virtual loss on the whole path (mcts.py:196-199), masked softmax
+// (mcts.py:72-89, including numpy's pairwise summation order), root noise (mcts.py:121-124), top-k
+// with forced pass (mcts.py:126-132), expand-once for repeated leaves (mcts.py:159-161), revert +
+// backup in slot order (mcts.py:205-218). This file is compiled with -ffp-contract=off so every
+// product and sum is rounded separately, as in the Python code.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/azamd.h"
+#include "az_board.cuh"
+
+namespace az {
+
+thread_local std::string g_err;
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+#define HIP_TRY(x)                                                                              \
+    do {                                                                                        \
+        hipError_t e_ = (x);                                                                    \
+        if (e_ != hipSuccess)                                                                   \
+            return fail(AZ_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_));            \
+    } while (0)
+
+enum Phase { PH_IDLE = 0, PH_ROOT = 1, PH_SELECTED = 2, PH_NEED_SELECT = 3, PH_DONE = 4 };
+enum { ST_SIMS = 0, ST_ROWS, ST_ROWS_RAW, ST_DEPTH_SUM, ST_MAX_DEPTH, ST_MAX_NODES, ST_TERMINAL, ST_BATCHES };
+
+// Everything a kernel needs, passed by value.
+struct Dev {
+    int n, np, A, H, C, G, sims, B, K, dedup;
+    int npad, seen_cap, max_nodes, max_depth, max_rows, tab_len;
+    double komi, eps, one_minus_eps, vl;
+    const uint64_t* zob;
+    const double* pbc;  // log((N + c_base + 1) / c_base) + c_init, N = parent visits (host libm)
+    const double* sqn;  // sqrt(N + 1)
+    // root states
+    int8_t* board;   // [G][npad]
+    int8_t* hist;    // [G][H][npad], newest first
+    uint64_t* seen;  // [G][seen_cap]
+    uint64_t* hash;  // [G] board-only Zobrist hash
+    int* sc;         // [G][8] to_play, passes, move_count, caps_b, caps_w, last_move, hist_count, n_seen
+    // trees
+    double* prior; double* vsum; int* visits; int16_t* action; int* child_off; int16_t* n_child;  // [G][max_nodes]
+    int* n_nodes;     // [G]
+    uint8_t* active;  // [G]
+    // current batch
+    int* path;        // [G][B][max_depth] node indices, path[0] = 0 (root)
+    int* path_len;    // [G][B]
+    int* leaf_ref;    // [G][B] -1 = terminal, else slot whose row carries this slot's evaluation
+    double* term_value;  // [G][B]
+    int* n_unique;    // [G]
+    int* uniq_slot;   // [G][B]
+    int* row_off;     // [G+1]
+    int* row_game; int* row_slot;  // [max_rows]
+    uint8_t* row_legal;  // [max_rows][A]
+    int* ctl;         // [4] n_rows, error code, -, -
+    long long* stats; // [8]
+};
+
+__device__ inline int sc_idx(int g, int f) { return g * 8 + f; }
+enum { SC_TP = 0, SC_PASSES, SC_MOVES, SC_CAPB, SC_CAPW, SC_LAST, SC_HIST, SC_SEEN };
+
+// ------------------------------------------------------------------------------------------------
+// A game state being replayed inside one wave: board in LDS, scalars in registers (wave-uniform).
+template <int PPL>
+struct Sim {
+    uint64_t hash;
+    int tp, passes, moves, capb, capw, last, ns;
+};
+
+template <int PPL>
+__device__ inline void sim_load_root(const Dev& d, int g, int lane, const Geo<PPL>& geo, BoardLds<PPL>& b,
+                                     uint64_t* seen_lds, Sim<PPL>& s) {
+#pragma unroll
+    for (int k = 0; k < PPL; ++k)
+        if (geo.p[k] >= 0) b.col[geo.p[k]] = d.board[(size_t)g * d.npad + geo.p[k]];
+    s.tp = d.sc[sc_idx(g, SC_TP)];
+    s.passes = d.sc[sc_idx(g, SC_PASSES)];
+    s.moves = d.sc[sc_idx(g, SC_MOVES)];
+    s.capb = d.sc[sc_idx(g, SC_CAPB)];
+    s.capw = d.sc[sc_idx(g, SC_CAPW)];
+    s.last = d.sc[sc_idx(g, SC_LAST)];
+    s.ns = d.sc[sc_idx(g, SC_SEEN)];
+    s.hash = d.hash[g];
+    for (int i = lane; i < s.ns; i += 64) seen_lds[i] = d.seen[(size_t)g * d.seen_cap + i];
+    __syncthreads();
+}
+
+template <int PPL>
+__device__ inline bool sim_terminal(const Dev& d, const Sim<PPL>& s) {
+    return s.passes >= 2 || s.moves >= 2 * d.np;  // go.py:205-206
+}
+
+// go.py:159-203 on the replayed state. `hist_lds` (may be null) holds H boards newest first.
+template <int PPL>
+__device__ inline void sim_play(const Dev& d, int lane, const Geo<PPL>& geo, BoardLds<PPL>& b, uint64_t* seen_lds,
+                                int8_t* hist_lds, Sim<PPL>& s, int action) {
+    if (action == d.np) {
+        s.passes += 1;
+        s.last = -1;
+    } else {
+        analyze<PPL, false>(geo, b, d.zob);
+        const int cap = place_stone<PPL>(geo, b, d.zob, d.n, lane, action, s.tp, s.hash);
+        if (s.tp > 0) s.capb += cap; else s.capw += cap;
+        s.passes = 0;
+        s.last = action;
+    }
+    s.tp = -s.tp;
+    s.moves += 1;
+    if (lane == 0) seen_lds[s.ns] = s.hash ^ d.zob[kZobSide + (s.tp < 0)];
+    s.ns += 1;
+    if (hist_lds) {
+        for (int i = d.H - 1; i >= 1; --i) {
+#pragma unroll
+            for (int k = 0; k < PPL; ++k)
+                if (geo.p[k] >= 0) hist_lds[i * BoardLds<PPL>::NPAD + geo.p[k]] = hist_lds[(i - 1) * BoardLds<PPL>::NPAD + geo.p[k]];
+        }
+#pragma unroll
+        for (int k = 0; k < PPL; ++k)
+            if (geo.p[k] >= 0) hist_lds[geo.p[k]] = b.col[geo.p[k]];
+    }
+    __syncthreads();
+}
+
+// go.py:251-263 for a terminal replayed state.
+template <int PPL>
+__device__ inline double sim_outcome(const Dev& d, const Geo<PPL>& geo, BoardLds<PPL>& b, const Sim<PPL>& s,
+                                     double* black_out = nullptr, double* white_out = nullptr) {
+    analyze<PPL, true>(geo, b, d.zob);
+    int bs, ws;
+    area_score<PPL>(geo, b, bs, ws);
+    const double black = (double)bs, white = (double)ws + d.komi;
+    if (black_out) { *black_out = black; *white_out = white; }
+    const int w = black > white ? 1 : (white > black ? -1 : 0);
+    return w == 0 ? 0.0 : (w == s.tp ? 1.0 : -1.0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Root-state kernels
+template <int PPL>
+__global__ __launch_bounds__(64) void k_reset(Dev d, const uint8_t* mask) {
+    const int g = blockIdx.x, lane = threadIdx.x;
+    if (mask && !mask[g]) return;
+    for (int i = lane; i < d.npad; i += 64) d.board[(size_t)g * d.npad + i] = 0;
+    for (int i = lane; i < d.H * d.npad; i += 64) d.hist[(size_t)g * d.H * d.npad + i] = 0;
+    if (lane == 0) {
+        int* sc = d.sc + g * 8;
+        sc[SC_TP] = 1; sc[SC_PASSES] = 0; sc[SC_MOVES] = 0; sc[SC_CAPB] = 0; sc[SC_CAPW] = 0;
+        sc[SC_LAST] = -1; sc[SC_HIST] = 1; sc[SC_SEEN] = 1;
+        d.hash[g] = 0;
+        d.seen[(size_t)g * d.seen_cap] = d.zob[kZobSide + 0];  // empty board, Black to move
+    }
+}
+
+template <int PPL>
+__global__ __launch_bounds__(64) void k_play(Dev d, const int* actions, int* status) {
+    __shared__ BoardLds<PPL> b;
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+    uint64_t* seen_lds = (uint64_t*)dyn;
+    const int g = blockIdx.x, lane = threadIdx.x;
+    const int a = actions[g];
+    if (a < 0) { if (status && lane == 0) status[g] = 0; return; }
+    Geo<PPL> geo;
+    geo_init<PPL>(geo, d.n, lane);
+    Sim<PPL> s;
+    sim_load_root<PPL>(d, g, lane, geo, b, seen_lds, s);
+    bool ok = a <= d.np && s.ns < d.seen_cap;
+    if (ok && a < d.np) {  // go.py:179-180: re-check legality
+        analyze<PPL, false>(geo, b, d.zob);
+        bool legal[PPL];
+        legal_points<PPL>(geo, b, d.zob, s.tp, s.hash, seen_lds, s.ns, legal);
+        bool mine = false;
+#pragma unroll
+        for (int k = 0; k < PPL; ++k)
+            if (geo.p[k] == a) mine = legal[k];
+        ok = __any(mine);
+    }
+    if (!ok) { if (status && lane == 0) status[g] = AZ_ERR_ILLEGAL; return; }
+    const int ns0 = s.ns;
+    sim_play<PPL>(d, lane, geo, b, seen_lds, nullptr, s, a);
+    // write back
+    int8_t* hist = d.hist + (size_t)g * d.H * d.npad;
+    for (int i = d.H - 1; i >= 1; --i)
+#pragma unroll
+        for (int k = 0; k < PPL; ++k)
+            if (geo.p[k] >= 0) hist[i * d.npad + geo.p[k]] = hist[(i - 1) * d.npad + geo.p[k]];
+#pragma unroll
+    for (int k = 0; k < PPL; ++k)
+        if (geo.p[k] >= 0) {
+            const int8_t v = b.col[geo.p[k]];
+            d.board[(size_t)g * d.npad + geo.p[k]] = v;
+            hist[geo.p[k]] = v;
+        }
+    if (lane == 0) {
+        int* sc = d.sc + g * 8;
+        // the seen list stands for a set (go.py:173/:199): skip keys already present
+        const uint64_t key = seen_lds[ns0];
+        bool dup = false;
+        for (int i = 0; i < ns0; ++i) dup |= seen_lds[i] == key;
+        if (!dup) { d.seen[(size_t)g * d.seen_cap + ns0] = key; sc[SC_SEEN] = ns0 + 1; }
+        sc[SC_TP] = s.tp; sc[SC_PASSES] = s.passes; sc[SC_MOVES] = s.moves; sc[SC_CAPB] = s.capb;
+        sc[SC_CAPW] = s.capw; sc[SC_LAST] = s.last;
+        sc[SC_HIST] = min(sc[SC_HIST] + 1, d.H);
+        d.hash[g] = s.hash;
+        if (status) status[g] = 0;
+    }
+}
+
+// Feature planes + legal mask of one replayed state (go.py:265-304). mask_out may be null.
+template <int PPL>
+__device__ inline int emit_features(const Dev& d, int lane, const Geo<PPL>& geo, BoardLds<PPL>& b,
+                                    const uint64_t* seen_lds, const int8_t* hist, int hist_stride, int hist_count,
+                                    const Sim<PPL>& s, void* out_row, int layout, uint8_t* mask_out) {
+    analyze<PPL, false>(geo, b, d.zob);
+    bool legal[PPL];
+    legal_points<PPL>(geo, b, d.zob, s.tp, s.hash, seen_lds, s.ns, legal);
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < PPL; ++k) cnt += legal[k] ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if (mask_out) {
+#pragma unroll
+        for (int k = 0; k < PPL; ++k)
+            if (geo.p[k] >= 0) mask_out[geo.p[k]] = legal[k] ? 1 : 0;
+        if (lane == 0) mask_out[d.np] = 1;
+    }
+    if (out_row) {
+        const double max_pts = (double)(d.np > 1 ? d.np : 1);
+        const int own = s.tp > 0 ? s.capb : s.capw, opp = s.tp > 0 ? s.capw : s.capb;
+        const float f_own = (float)((double)own / max_pts), f_opp = (float)((double)opp / max_pts);
+        const float f_tp = s.tp > 0 ? 1.0f : 0.0f;
+        const int take = hist_count < d.H ? hist_count : d.H;
+        if (layout == AZ_FEAT_F32_NCHW) {
+            float* o = (float*)out_row;
+#pragma unroll
+            for (int k = 0; k < PPL; ++k) {
+                const int p = geo.p[k];
+                if (p < 0) continue;
+                for (int i = 0; i < d.H; ++i) {
+                    const int v = i < take ? hist[i * hist_stride + p] : 0;
+                    o[i * d.np + p] = (v != 0 && v == s.tp) ? 1.0f : 0.0f;
+                    o[(d.H + i) * d.np + p] = (v != 0 && v == -s.tp) ? 1.0f : 0.0f;
+                }
+                o[(2 * d.H) * d.np + p] = f_tp;
+                o[(2 * d.H + 1) * d.np + p] = legal[k] ? 1.0f : 0.0f;
+                o[(2 * d.H + 2) * d.np + p] = p == s.last ? 1.0f : 0.0f;
+                o[(2 * d.H + 3) * d.np + p] = f_own;
+                o[(2 * d.H + 4) * d.np + p] = f_opp;
+            }
+        } else {  // bf16 [np][cpad], channel-minor
+            const int cpad = d.C <= 32 ? 32 : 64;
+            uint16_t* o = (uint16_t*)out_row;
+            const uint16_t one = 0x3F80;
+            auto bf = [](float f) -> uint16_t {  // round to nearest even
+                uint32_t u = __float_as_uint(f);
+                return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+            };
+#pragma unroll
+            for (int k = 0; k < PPL; ++k) {
+                const int p = geo.p[k];
+                if (p < 0) continue;
+                uint16_t* op = o + (size_t)p * cpad;
+                for (int i = 0; i < d.H; ++i) {
+                    const int v = i < take ? hist[i * hist_stride + p] : 0;
+                    op[i] = (v != 0 && v == s.tp) ? one : 0;
+                    op[d.H + i] = (v != 0 && v == -s.tp) ? one : 0;
+                }
+                op[2 * d.H] = s.tp > 0 ? one : 0;
+                op[2 * d.H + 1] = legal[k] ? one : 0;
+                op[2 * d.H + 2] = p == s.last ? one : 0;
+                op[2 * d.H + 3] = bf(f_own);
+                op[2 * d.H + 4] = bf(f_opp);
+                for (int c = d.C; c < cpad; ++c) op[c] = 0;
+            }
+        }
+    }
+    return cnt + 1;  // + pass
+}
+
+template <int PPL>
+__global__ __launch_bounds__(64) void k_root_features(Dev d, void* out, int layout, uint8_t* mask_out) {
+    __shared__ BoardLds<PPL> b;
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+    uint64_t* seen_lds = (uint64_t*)dyn;
+    const int g = blockIdx.x, lane = threadIdx.x;
+    Geo<PPL> geo;
+    geo_init<PPL>(geo, d.n, lane);
+    Sim<PPL> s;
+    sim_load_root<PPL>(d, g, lane, geo, b, seen_lds, s);
+    const size_t row_bytes = layout == AZ_FEAT_F32_NCHW ? (size_t)d.C * d.np * 4 : (size_t)d.np * (d.C <= 32 ? 32 : 64) * 2;
+    emit_features<PPL>(d, lane, geo, b, seen_lds, d.hist + (size_t)g * d.H * d.npad, d.npad, d.sc[sc_idx(g, SC_HIST)], s,
+                       out ? (unsigned char*)out + (size_t)g * row_bytes : nullptr, layout,
+                       mask_out ? mask_out + (size_t)g * d.A : nullptr);
+}
+
+template <int PPL>
+__global__ __launch_bounds__(64) void k_status(Dev d, double* score, int* info) {
+    __shared__ BoardLds<PPL> b;
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+    uint64_t* seen_lds = (uint64_t*)dyn;
+    const int g = blockIdx.x, lane = threadIdx.x;
+    Geo<PPL> geo;
+    geo_init<PPL>(geo, d.n, lane);
+    Sim<PPL> s;
+    sim_load_root<PPL>(d, g, lane, geo, b, seen_lds, s);
+    double bl, wh;
+    sim_outcome<PPL>(d, geo, b, s, &bl, &wh);
+    if (lane == 0) {
+        if (score) { score[2 * g] = bl; score[2 * g + 1] = wh; }
+        if (info) {
+            int* o = info + g * 8;
+            o[0] = s.tp; o[1] = s.passes; o[2] = s.moves; o[3] = s.capb; o[4] = s.capw; o[5] = s.last;
+            o[6] = sim_terminal<PPL>(d, s) ? 1 : 0;
+            o[7] = bl > wh ? 1 : (wh > bl ? -1 : 0);
+        }
+    }
+}
+
+__global__ void k_export(Dev d, int8_t* board, int8_t* hist, int* scalars, uint64_t* seen) {
+    const int g = blockIdx.x;
+    for (int i = threadIdx.x; i < d.np; i += blockDim.x) board[(size_t)g * d.np + i] = d.board[(size_t)g * d.npad + i];
+    for (int i = threadIdx.x; i < d.H * d.np; i += blockDim.x)
+        hist[(size_t)g * d.H * d.np + i] = d.hist[((size_t)g * d.H + i / d.np) * d.npad + i % d.np];
+    for (int i = threadIdx.x; i < 8; i += blockDim.x) scalars[g * 8 + i] = d.sc[g * 8 + i];
+    const int ns = d.sc[sc_idx(g, SC_SEEN)];
+    for (int i = threadIdx.x; i < d.seen_cap; i += blockDim.x)
+        seen[(size_t)g * d.seen_cap + i] = i < ns ? d.seen[(size_t)g * d.seen_cap + i] : 0;
+}
+
+__global__ void k_import(Dev d, const int8_t* board, const int8_t* hist, const int* scalars, const uint64_t* seen) {
+    const int g = blockIdx.x;
+    __shared__ unsigned long long hsh;
+    if (threadIdx.x == 0) hsh = 0;
+    __syncthreads();
+    unsigned long long h = 0;
+    for (int i = threadIdx.x; i < d.npad; i += blockDim.x) {
+        const int8_t v = i < d.np ? board[(size_t)g * d.np + i] : 0;
+        d.board[(size_t)g * d.npad + i] = v;
+        if (v != 0) h ^= d.zob[2 * i + (v < 0)];
+    }
+    atomicXor(&hsh, h);
+    for (int i = threadIdx.x; i < d.H * d.npad; i += blockDim.x) {
+        const int hi = i / d.npad, p = i % d.npad;
+        d.hist[(size_t)g * d.H * d.npad + i] = p < d.np ? hist[((size_t)g * d.H + hi) * d.np + p] : 0;
+    }
+    for (int i = threadIdx.x; i < 8; i += blockDim.x) d.sc[g * 8 + i] = scalars[g * 8 + i];
+    for (int i = threadIdx.x; i < d.seen_cap; i += blockDim.x) d.seen[(size_t)g * d.seen_cap + i] = seen[(size_t)g * d.seen_cap + i];
+    __syncthreads();
+    if (threadIdx.x == 0) d.hash[g] = hsh;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Search kernels
+__global__ __launch_bounds__(64) void k_begin(Dev d, const uint8_t* enable) {
+    const int g = blockIdx.x * 64 + threadIdx.x;
+    if (g == 0) {
+        for (int i = 0; i < 8; ++i) d.stats[i] = 0;
+        d.ctl[1] = 0;
+    }
+    if (g >= d.G) return;
+    const int* sc = d.sc + g * 8;
+    const bool terminal = sc[SC_PASSES] >= 2 || sc[SC_MOVES] >= 2 * d.np;
+    const bool act = !terminal && (!enable || enable[g]);
+    d.active[g] = act ? 1 : 0;
+    const size_t base = (size_t)g * d.max_nodes;
+    d.prior[base] = 1.0; d.vsum[base] = 0.0; d.visits[base] = 0; d.action[base] = -1;  // mcts.py:171
+    d.child_off[base] = 0; d.n_child[base] = 0;
+    d.n_nodes[g] = 1;
+    d.n_unique[g] = act ? 1 : 0;  // the root evaluation is the first pending row
+}
+
+// Exclusive scan of n_unique over games -> row offsets, row->(game, slot) tables, row count.
+__global__ __launch_bounds__(1024) void k_scan_rows(Dev d, int root_phase) {
+    __shared__ int part[1024];
+    const int t = threadIdx.x;
+    const int per = (d.G + 1023) / 1024;
+    const int lo = min(t * per, d.G), hi = min(lo + per, d.G);
+    int sum = 0;
+    for (int g = lo; g < hi; ++g) sum += d.n_unique[g];
+    part[t] = sum;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        int v = t >= o ? part[t - o] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int off = part[t] - sum;
+    for (int g = lo; g < hi; ++g) {
+        d.row_off[g] = off;
+        const int nu = d.n_unique[g];
+        for (int u = 0; u < nu; ++u) {
+            d.row_game[off + u] = g;
+            d.row_slot[off + u] = root_phase ? -1 : d.uniq_slot[g * d.B + u];
+        }
+        off += nu;
+    }
+    if (t == 1023) { d.row_off[d.G] = part[1023]; d.ctl[0] = part[1023]; }
+}
+
+// (score, index) arg-max over the wave: largest score, smallest index among equals.
+__device__ inline void wave_argmax(double& s, int& idx) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double os = __shfl_xor(s, o);
+        const int oi = __shfl_xor(idx, o);
+        if (os > s || (os == s && oi < idx)) { s = os; idx = oi; }
+    }
+}
+
+// mcts.py:181-199: batch_n descents for game blockIdx.x.
+template <int PPL>
+__global__ __launch_bounds__(64) void k_select(Dev d, int batch_n) {
+    __shared__ BoardLds<PPL> b;
+    __shared__ int8_t root_col[BoardLds<PPL>::NPAD];
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+    uint64_t* seen_lds = (uint64_t*)dyn;
+    const int g = blockIdx.x, lane = threadIdx.x;
+    if (!d.active[g]) { if (lane == 0) d.n_unique[g] = 0; return; }
+    Geo<PPL> geo;
+    geo_init<PPL>(geo, d.n, lane);
+    Sim<PPL> root;
+    sim_load_root<PPL>(d, g, lane, geo, b, seen_lds, root);
+#pragma unroll
+    for (int k = 0; k < PPL; ++k)
+        if (geo.p[k] >= 0) root_col[geo.p[k]] = b.col[geo.p[k]];
+    __syncthreads();
+
+    const size_t nb = (size_t)g * d.max_nodes;
+    double* prior = d.prior + nb; double* vsum = d.vsum + nb; int* visits = d.visits + nb;
+    const int16_t* action = d.action + nb; const int* child_off = d.child_off + nb; const int16_t* n_child = d.n_child + nb;
+    int n_unique = 0, depth_sum = 0, max_depth = 0, n_term = 0;
+
+    for (int slot = 0; slot < batch_n; ++slot) {
+        Sim<PPL> s = root;
+#pragma unroll
+        for (int k = 0; k < PPL; ++k)
+            if (geo.p[k] >= 0) b.col[geo.p[k]] = root_col[geo.p[k]];
+        __syncthreads();
+        int* path = d.path + ((size_t)g * d.B + slot) * d.max_depth;
+        int node = 0, len = 1;
+        if (lane == 0) path[0] = 0;
+        bool failed = false;
+        while (true) {
+            const int nc = n_child[node];
+            if (nc == 0 || sim_terminal<PPL>(d, s) || len >= d.max_depth) break;
+            // mcts.py:97-116
+            const int first = child_off[node];
+            int pv = visits[node];
+            pv = pv < d.tab_len ? pv : d.tab_len - 1;
+            const double pbc = d.pbc[pv], sq = d.sqn[pv];
+            double best = -INFINITY;
+            int best_i = 0x7fffffff;
+            for (int i0 = 0; i0 < nc; i0 += 64) {
+                const int i = i0 + lane;
+                if (i < nc) {
+                    const int vc = visits[first + i];
+                    double pb = pbc * (sq / ((double)vc + 1.0));
+                    const double prior_score = pb * prior[first + i];
+                    const double value_score = -(vc == 0 ? 0.0 : vsum[first + i] / (double)vc);
+                    const double score = prior_score + value_score;
+                    if (score > -1e18 && (score > best)) { best = score; best_i = i; }
+                }
+            }
+            wave_argmax(best, best_i);
+            if (best_i == 0x7fffffff) { failed = true; break; }  // mcts.py:114-115
+            node = first + best_i;
+            sim_play<PPL>(d, lane, geo, b, seen_lds, nullptr, s, (int)action[node]);
+            if (lane == 0) path[len] = node;
+            len += 1;
+        }
+        if (failed) { if (lane == 0) atomicMin(&d.ctl[1], (int)AZ_ERR_NOCHILD); }
+        const int gs = g * d.B + slot;
+        int ref;
+        if (sim_terminal<PPL>(d, s)) {  // mcts.py:191-192
+            const double v = sim_outcome<PPL>(d, geo, b, s);
+            if (lane == 0) d.term_value[gs] = v;
+            ref = -1;
+            n_term += 1;
+        } else {
+            ref = slot;
+            if (d.dedup) {
+                for (int u = 0; u < n_unique; ++u) {
+                    const int us = d.uniq_slot[g * d.B + u];
+                    const int* up = d.path + ((size_t)g * d.B + us) * d.max_depth;
+                    if (up[d.path_len[g * d.B + us] - 1] == node) { ref = us; break; }
+                }
+            }
+            if (ref == slot) {
+                if (lane == 0) d.uniq_slot[g * d.B + n_unique] = slot;
+                n_unique += 1;
+            }
+        }
+        if (lane == 0) { d.path_len[gs] = len; d.leaf_ref[gs] = ref; }
+        depth_sum += len - 1;
+        max_depth = max(max_depth, len - 1);
+        __syncthreads();
+        if (d.vl > 0.0) {  // mcts.py:196-199
+            for (int i = lane; i < len; i += 64) {
+                const int pn = path[i];
+                visits[pn] += 1;
+                vsum[pn] -= d.vl;
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    if (lane == 0) {
+        d.n_unique[g] = n_unique;
+        atomicAdd((unsigned long long*)&d.stats[ST_DEPTH_SUM], (unsigned long long)depth_sum);
+        atomicMax((unsigned long long*)&d.stats[ST_MAX_DEPTH], (unsigned long long)max_depth);
+        atomicAdd((unsigned long long*)&d.stats[ST_TERMINAL], (unsigned long long)n_term);
+        atomicAdd((unsigned long long*)&d.stats[ST_SIMS], (unsigned long long)batch_n);
+        int raw = batch_n - n_term;
+        atomicAdd((unsigned long long*)&d.stats[ST_ROWS_RAW], (unsigned long long)raw);
+        atomicAdd((unsigned long long*)&d.stats[ST_ROWS], (unsigned long long)n_unique);
+    }
+}
+
+// Leaf gather: one wave per pending row replays the row's path from its game's root and writes the
+// feature planes (dense, row order) and the legal mask.
+template <int PPL>
+__global__ __launch_bounds__(64) void k_leaf(Dev d, void* out, int layout) {
+    __shared__ BoardLds<PPL> b;
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+    uint64_t* seen_lds = (uint64_t*)dyn;
+    int8_t* hist_lds = (int8_t*)(dyn + (size_t)d.seen_cap * 8);
+    const int r = blockIdx.x, lane = threadIdx.x;
+    if (r >= d.ctl[0]) return;
+    const int g = d.row_game[r], slot = d.row_slot[r];
+    Geo<PPL> geo;
+    geo_init<PPL>(geo, d.n, lane);
+    Sim<PPL> s;
+    sim_load_root<PPL>(d, g, lane, geo, b, seen_lds, s);
+    for (int i = lane; i < d.H * BoardLds<PPL>::NPAD; i += 64) {
+        const int hi = i / BoardLds<PPL>::NPAD, p = i % BoardLds<PPL>::NPAD;
+        hist_lds[i] = d.hist[((size_t)g * d.H + hi) * d.npad + p];
+    }
+    int hist_count = d.sc[sc_idx(g, SC_HIST)];
+    __syncthreads();
+    if (slot >= 0) {
+        const int len = d.path_len[g * d.B + slot];
+        const int* path = d.path + ((size_t)g * d.B + slot) * d.max_depth;
+        const int16_t* action = d.action + (size_t)g * d.max_nodes;
+        for (int i = 1; i < len; ++i) {
+            sim_play<PPL>(d, lane, geo, b, seen_lds, hist_lds, s, (int)action[path[i]]);
+            hist_count = min(hist_count + 1, d.H);
+        }
+    }
+    const size_t row_bytes = layout == AZ_FEAT_F32_NCHW ? (size_t)d.C * d.np * 4 : (size_t)d.np * (d.C <= 32 ? 32 : 64) * 2;
+    emit_features<PPL>(d, lane, geo, b, seen_lds, hist_lds, BoardLds<PPL>::NPAD, hist_count, s,
+                       (unsigned char*)out + (size_t)r * row_bytes, layout, d.row_legal + (size_t)r * d.A);
+}
+
+// numpy pairwise summation of a contiguous float64 vector (ndarray.sum(), mcts.py:80).
+__device__ inline double pw_block(const double* a, int n) {
+    if (n < 8) {
+        double r = 0.0;
+        for (int i = 0; i < n; ++i) r += a[i];
+        return r;
+    }
+    double r0 = a[0], r1 = a[1], r2 = a[2], r3 = a[3], r4 = a[4], r5 = a[5], r6 = a[6], r7 = a[7];
+    int i;
+    for (i = 8; i < n - (n % 8); i += 8) {
+        r0 += a[i]; r1 += a[i + 1]; r2 += a[i + 2]; r3 += a[i + 3];
+        r4 += a[i + 4]; r5 += a[i + 5]; r6 += a[i + 6]; r7 += a[i + 7];
+    }
+    double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    for (; i < n; ++i) res += a[i];
+    return res;
+}
+__device__ inline double pw_l2(const double* a, int n) {
+    if (n <= 128) return pw_block(a, n);
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    return pw_block(a, n2) + pw_block(a + n2, n - n2);
+}
+__device__ inline double pw_sum(const double* a, int n) {  // n <= 512
+    if (n <= 128) return pw_block(a, n);
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    return pw_l2(a, n2) + pw_l2(a + n2, n - n2);
+}
+
+// mcts.py:66-91 + :118-137 for one node: masked softmax (float64), optional noise, top-k, children.
+// p_lds: double[A] work array; runs on the whole wave.
+__device__ inline void expand_node(const Dev& d, int g, int lane, int node, const float* logits, const uint8_t* legal,
+                                   const double* noise, double* p_lds, int* ord_lds, double* priors_out) {
+    const int A = d.A;
+    __shared__ double s_bcast[2];
+    double mx = -INFINITY;
+    for (int a = lane; a < A; a += 64) {
+        const double m = (double)logits[a] + (legal[a] ? 0.0 : -1e9);
+        p_lds[a] = m;
+        mx = fmax(mx, m);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
+    for (int a = lane; a < A; a += 64) p_lds[a] = exp(p_lds[a] - mx);
+    __syncthreads();
+    if (lane == 0) s_bcast[0] = pw_sum(p_lds, A);
+    __syncthreads();
+    const double sum = s_bcast[0];
+    int nl = 0;
+    for (int a0 = 0; a0 < A; a0 += 64) {
+        const int a = a0 + lane;
+        const bool lg = a < A && legal[a];
+        nl += __popcll(__ballot(lg));
+    }
+    for (int a = lane; a < A; a += 64) {
+        if (sum <= 0) p_lds[a] = legal[a] ? 1.0 / (double)nl : 0.0;
+        else p_lds[a] = p_lds[a] / sum;
+    }
+    __syncthreads();
+    if (noise) {  // mcts.py:121-124: noise[i] belongs to the i-th legal action
+        int base = 0;
+        for (int a0 = 0; a0 < A; a0 += 64) {
+            const int a = a0 + lane;
+            const bool lg = a < A && legal[a];
+            const unsigned long long bal = __ballot(lg);
+            if (lg) {
+                const int i = base + __popcll(bal & ((1ull << lane) - 1ull));
+                p_lds[a] = d.one_minus_eps * p_lds[a] + d.eps * noise[i];
+            }
+            base += __popcll(bal);
+        }
+        __syncthreads();
+    }
+    if (priors_out)
+        for (int a = lane; a < A; a += 64) priors_out[a] = 0.0;
+    const bool already = d.n_child[(size_t)g * d.max_nodes + node] > 0;  // mcts.py:160
+    // child order: legal order, or rank by (prior desc, action asc) cut to K with the pass forced in
+    int cnt = nl;
+    const bool topk = d.K > 0 && nl > d.K;
+    if (topk) cnt = d.K;
+    int first = 0;
+    if (!already) {
+        if (lane == 0) {
+            first = d.n_nodes[g];
+            if (first + cnt > d.max_nodes) { atomicMin(&d.ctl[1], (int)AZ_ERR_CAPACITY); first = -1; }
+            else d.n_nodes[g] = first + cnt;
+        }
+        first = __shfl(first, 0);
+        if (first < 0) return;
+    }
+    const size_t nbase = (size_t)g * d.max_nodes;
+    int base = 0;
+    for (int a0 = 0; a0 < A; a0 += 64) {
+        const int a = a0 + lane;
+        const bool lg = a < A && legal[a];
+        const unsigned long long bal = __ballot(lg);
+        if (lg) {
+            int pos;
+            if (!topk) {
+                pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+            } else {
+                const double pa = p_lds[a];
+                int rank = 0;
+                for (int x = 0; x < A; ++x) {
+                    if (!legal[x]) continue;
+                    const double px = p_lds[x];
+                    rank += (px > pa || (px == pa && x < a)) ? 1 : 0;
+                }
+                pos = rank;
+                if (a == A - 1 && rank >= cnt) pos = cnt - 1;  // pass replaces the last kept action
+                else if (rank >= cnt) pos = -1;
+                else if (rank == cnt - 1) {  // am I displaced by the pass?
+                    const double pp = p_lds[A - 1];
+                    int prank = 0;
+                    for (int x = 0; x < A - 1; ++x) {
+                        if (!legal[x]) continue;
+                        const double px = p_lds[x];
+                        prank += (px > pp || px == pp) ? 1 : 0;
+                    }
+                    if (prank >= cnt) pos = -1;
+                }
+            }
+            if (pos >= 0) {
+                if (priors_out) priors_out[a] = p_lds[a];
+                if (!already) {
+                    const size_t c = nbase + first + pos;
+                    d.prior[c] = p_lds[a]; d.vsum[c] = 0.0; d.visits[c] = 0; d.action[c] = (int16_t)a;
+                    d.child_off[c] = 0; d.n_child[c] = 0;
+                }
+            }
+        }
+        base += __popcll(bal);
+    }
+    (void)ord_lds;
+    if (!already && lane == 0) {
+        d.child_off[nbase + node] = first;
+        d.n_child[nbase + node] = (int16_t)cnt;
+        atomicMax((unsigned long long*)&d.stats[ST_MAX_NODES], (unsigned long long)(first + cnt));
+    }
+    __threadfence_block();
+    __syncthreads();
+}
+
+// Root expansion (mcts.py:172): one wave per game.
+__global__ __launch_bounds__(64) void k_expand_root(Dev d, const float* logits, const double* noise, double* priors_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+    double* p_lds = (double*)dyn;
+    const int g = blockIdx.x, lane = threadIdx.x;
+    if (!d.active[g]) return;
+    const int r = d.row_off[g];
+    expand_node(d, g, lane, 0, logits + (size_t)r * d.A, d.row_legal + (size_t)r * d.A,
+                noise ? noise + (size_t)g * d.A : nullptr, p_lds, nullptr, priors_out ? priors_out + (size_t)r * d.A : nullptr);
+}
+
+// Expand the batch's leaves, then revert virtual loss and back up in slot order (mcts.py:203-218).
+__global__ __launch_bounds__(64) void k_expand_backup(Dev d, const float* logits, const float* values, int batch_n,
+                                                      double* priors_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
+    double* p_lds = (double*)dyn;
+    const int g = blockIdx.x, lane = threadIdx.x;
+    if (!d.active[g]) return;
+    const int nu = d.n_unique[g], r0 = d.row_off[g];
+    for (int u = 0; u < nu; ++u) {
+        const int slot = d.uniq_slot[g * d.B + u];
+        const int* path = d.path + ((size_t)g * d.B + slot) * d.max_depth;
+        const int node = path[d.path_len[g * d.B + slot] - 1];
+        expand_node(d, g, lane, node, logits + (size_t)(r0 + u) * d.A, d.row_legal + (size_t)(r0 + u) * d.A, nullptr, p_lds,
+                    nullptr, priors_out ? priors_out + (size_t)(r0 + u) * d.A : nullptr);
+    }
+    const size_t nb = (size_t)g * d.max_nodes;
+    double* vsum = d.vsum + nb;
+    int* visits = d.visits + nb;
+    for (int slot = 0; slot < batch_n; ++slot) {
+        const int gs = g * d.B + slot;
+        const int ref = d.leaf_ref[gs];
+        double value;
+        if (ref < 0) value = d.term_value[gs];
+        else {
+            int u = 0;
+            for (; u < nu; ++u) if (d.uniq_slot[g * d.B + u] == ref) break;
+            value = (double)values[r0 + u];
+        }
+        const int len = d.path_len[gs];
+        const int* path = d.path + (size_t)gs * d.max_depth;
+        for (int i = lane; i < len; i += 64) {
+            const int pn = path[i];
+            int vc = visits[pn];
+            double vs = vsum[pn];
+            if (d.vl > 0.0) { vc -= 1; vs += d.vl; }
+            const double v = ((len - 1 - i) & 1) ? -value : value;
+            visits[pn] = vc + 1;
+            vsum[pn] = vs + v;
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(64) void k_root_counts(Dev d, int* counts) {
+    const int g = blockIdx.x, lane = threadIdx.x;
+    if (!d.active[g]) { if (lane == 0) counts[g] = 0; return; }
+    const uint8_t* legal = d.row_legal + (size_t)d.row_off[g] * d.A;
+    int c = 0;
+    for (int a = lane; a < d.A; a += 64) c += legal[a];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if (lane == 0) counts[g] = c;
+}
+
+__global__ __launch_bounds__(64) void k_result(Dev d, int* visits_out, double* root_value) {
+    const int g = blockIdx.x, lane = threadIdx.x;
+    for (int a = lane; a < d.A; a += 64) visits_out[(size_t)g * d.A + a] = 0;
+    if (!d.active[g]) { if (lane == 0) root_value[g] = 0.0; return; }
+    __syncthreads();
+    const size_t nb = (size_t)g * d.max_nodes;
+    const int first = d.child_off[nb], nc = d.n_child[nb];
+    for (int i = lane; i < nc; i += 64) visits_out[(size_t)g * d.A + d.action[nb + first + i]] = d.visits[nb + first + i];
+    if (lane == 0) root_value[g] = d.visits[nb] == 0 ? 0.0 : d.vsum[nb] / (double)d.visits[nb];  // mcts.py:24-27
+}
+
+}  // namespace az
+
+// =================================================================================================
+// Host side
+using namespace az;
+
+struct az_engine {
+    az_config cfg;
+    Dev d;
+    int ppl;
+    int phase = PH_IDLE;
+    int sims_done = 0, batch_n = 0;
+    int pending_rows = 0;
+    bool rows_known = false;
+    int* ctl_host = nullptr;        // pinned
+    long long* stats_host = nullptr;
+    double* last_priors = nullptr;  // [max_rows][A]
+    std::vector<void*> allocs;
+};
+
+#define DISPATCH_PPL(e, KERNEL, grid, shmem, stream, ...)                                              \
+    do {                                                                                               \
+        switch ((e)->ppl) {                                                                            \
+            case 1: hipLaunchKernelGGL((KERNEL<1>), dim3(grid), dim3(64), shmem, (hipStream_t)stream, __VA_ARGS__); break; \
+            case 2: hipLaunchKernelGGL((KERNEL<2>), dim3(grid), dim3(64), shmem, (hipStream_t)stream, __VA_ARGS__); break; \
+            case 3: hipLaunchKernelGGL((KERNEL<3>), dim3(grid), dim3(64), shmem, (hipStream_t)stream, __VA_ARGS__); break; \
+            default: hipLaunchKernelGGL((KERNEL<6>), dim3(grid), dim3(64), shmem, (hipStream_t)stream, __VA_ARGS__); break; \
+        }                                                                                              \
+    } while (0)
+
+template <typename T>
+static int dev_alloc(az_engine* e, T** p, size_t count) {
+    void* q = nullptr;
+    HIP_TRY(hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T)));
+    e->allocs.push_back(q);
+    *p = (T*)q;
+    return AZ_OK;
+}
+#define ALLOC(field, count)                                                \
+    do {                                                                   \
+        int rc_ = dev_alloc(e, &e->d.field, (size_t)(count));              \
+        if (rc_ != AZ_OK) { az_engine_destroy(e); return rc_; }            \
+    } while (0)
+
+extern "C" {
+
+const char* az_last_error(void) { return g_err.c_str(); }
+uint64_t az_zobrist_key(int32_t index) { return zobrist_key(index); }
+
+int az_engine_create(const az_config* c, az_engine** out) {
+    if (!c || !out) return fail(AZ_ERR_ARG, "null argument");
+    if (c->board_size < 2 || c->board_size > 19) return fail(AZ_ERR_ARG, "board_size must be 2..19");
+    if (c->history_len < 1 || c->history_len > 16) return fail(AZ_ERR_ARG, "history_len must be 1..16");
+    if (c->games < 1) return fail(AZ_ERR_ARG, "games must be >= 1");
+    if (c->simulations < 0) return fail(AZ_ERR_ARG, "simulations must be >= 0");
+    HIP_TRY(hipSetDevice(c->device));
+    az_engine* e = new az_engine();
+    e->cfg = *c;
+    Dev& d = e->d;
+    memset(&d, 0, sizeof(d));
+    d.n = c->board_size; d.np = d.n * d.n; d.A = d.np + 1; d.H = c->history_len; d.C = 2 * d.H + 5; d.G = c->games;
+    d.sims = c->simulations;
+    d.B = std::max(1, c->inference_batch);          // mcts.py:53
+    d.K = std::max(0, c->topk_expand);              // mcts.py:54
+    d.vl = std::max(0.0, c->virtual_loss);          // mcts.py:55
+    d.dedup = c->dedup_leaves ? 1 : 0;
+    d.komi = c->komi; d.eps = c->dirichlet_eps; d.one_minus_eps = 1 - c->dirichlet_eps;
+    e->ppl = d.np <= 64 ? 1 : d.np <= 128 ? 2 : d.np <= 192 ? 3 : 6;
+    d.npad = 64 * e->ppl;
+    d.seen_cap = 2 * d.np + 2;
+    const int kc = d.K > 0 ? std::min(d.K, d.A) : d.A;
+    d.max_nodes = 1 + (d.sims + 1) * kc;
+    d.max_depth = std::min(d.sims, 2 * d.np) + 2;
+    d.max_rows = d.G * d.B;
+    d.tab_len = d.sims + d.B + 2;
+
+    ALLOC(board, (size_t)d.G * d.npad); ALLOC(hist, (size_t)d.G * d.H * d.npad);
+    ALLOC(seen, (size_t)d.G * d.seen_cap); ALLOC(hash, d.G); ALLOC(sc, (size_t)d.G * 8);
+    const size_t nn = (size_t)d.G * d.max_nodes;
+    ALLOC(prior, nn); ALLOC(vsum, nn); ALLOC(visits, nn); ALLOC(action, nn); ALLOC(child_off, nn); ALLOC(n_child, nn);
+    ALLOC(n_nodes, d.G); ALLOC(active, d.G);
+    ALLOC(path, (size_t)d.G * d.B * d.max_depth); ALLOC(path_len, (size_t)d.G * d.B); ALLOC(leaf_ref, (size_t)d.G * d.B);
+    ALLOC(term_value, (size_t)d.G * d.B); ALLOC(n_unique, d.G); ALLOC(uniq_slot, (size_t)d.G * d.B);
+    ALLOC(row_off, d.G + 1); ALLOC(row_game, d.max_rows); ALLOC(row_slot, d.max_rows);
+    ALLOC(row_legal, (size_t)d.max_rows * d.A); ALLOC(ctl, 4); ALLOC(stats, 8);
+    {
+        int rc = dev_alloc(e, &e->last_priors, (size_t)d.max_rows * d.A);
+        if (rc != AZ_OK) { az_engine_destroy(e); return rc; }
+    }
+    // tables (host libm, like math.log / math.sqrt in mcts.py:104-105)
+    std::vector<uint64_t> zob(kZobSide + 2);
+    for (int i = 0; i < kZobSide + 2; ++i) zob[i] = zobrist_key(i);
+    std::vector<double> pbc(d.tab_len), sqn(d.tab_len);
+    for (int N = 0; N < d.tab_len; ++N) {
+        pbc[N] = log(((double)N + c->c_base + 1.0) / c->c_base) + c->c_init;
+        sqn[N] = sqrt((double)N + 1.0);
+    }
+    uint64_t* zdev; double *pdev, *sdev;
+    if (dev_alloc(e, &zdev, zob.size()) || dev_alloc(e, &pdev, pbc.size()) || dev_alloc(e, &sdev, sqn.size())) {
+        az_engine_destroy(e);
+        return AZ_ERR_HIP;
+    }
+    HIP_TRY(hipMemcpy(zdev, zob.data(), zob.size() * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(pdev, pbc.data(), pbc.size() * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(sdev, sqn.data(), sqn.size() * 8, hipMemcpyHostToDevice));
+    d.zob = zdev; d.pbc = pdev; d.sqn = sdev;
+    if (hipHostMalloc((void**)&e->ctl_host, 4 * sizeof(int)) != hipSuccess ||
+        hipHostMalloc((void**)&e->stats_host, 8 * sizeof(long long)) != hipSuccess) {
+        az_engine_destroy(e);
+        return fail(AZ_ERR_HIP, "hipHostMalloc failed");
+    }
+    HIP_TRY(hipMemset(d.ctl, 0, 4 * sizeof(int)));
+    HIP_TRY(hipMemset(d.stats, 0, 8 * sizeof(long long)));
+    *out = e;
+    int rc = az_rules_reset(e, nullptr, nullptr);
+    if (rc != AZ_OK) { az_engine_destroy(e); *out = nullptr; return rc; }
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    return AZ_OK;
+}
+
+int az_engine_destroy(az_engine* e) {
+    if (!e) return AZ_OK;
+    (void)hipSetDevice(e->cfg.device);
+    (void)hipDeviceSynchronize();
+    for (void* p : e->allocs) (void)hipFree(p);
+    if (e->ctl_host) (void)hipHostFree(e->ctl_host);
+    if (e->stats_host) (void)hipHostFree(e->stats_host);
+    delete e;
+    return AZ_OK;
+}
+
+int az_engine_action_size(const az_engine* e) { return e->d.A; }
+int az_engine_feature_planes(const az_engine* e) { return e->d.C; }
+int az_engine_seen_capacity(const az_engine* e) { return e->d.seen_cap; }
+int az_engine_max_rows(const az_engine* e) { return std::max(e->d.max_rows, e->d.G); }
+
+static size_t seen_bytes(const az_engine* e) { return (size_t)e->d.seen_cap * 8; }
+static int check_launch(const char* what) {
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return fail(AZ_ERR_HIP, std::string(what) + ": " + hipGetErrorString(err));
+    return AZ_OK;
+}
+
+int az_rules_reset(az_engine* e, const uint8_t* mask, void* stream) {
+    if (!e) return fail(AZ_ERR_ARG, "null engine");
+    DISPATCH_PPL(e, k_reset, e->d.G, 0, stream, e->d, mask);
+    e->phase = PH_IDLE;
+    return check_launch("k_reset");
+}
+
+int az_rules_play(az_engine* e, const int32_t* actions, int32_t* status, void* stream) {
+    if (!e || !actions) return fail(AZ_ERR_ARG, "null argument");
+    DISPATCH_PPL(e, k_play, e->d.G, seen_bytes(e), stream, e->d, actions, status);
+    e->phase = PH_IDLE;
+    return check_launch("k_play");
+}
+
+int az_rules_legal_mask(az_engine* e, uint8_t* mask, void* stream) {
+    if (!e || !mask) return fail(AZ_ERR_ARG, "null argument");
+    DISPATCH_PPL(e, k_root_features, e->d.G, seen_bytes(e), stream, e->d, (void*)nullptr, 0, mask);
+    return check_launch("k_root_features");
+}
+
+int az_rules_features(az_engine* e, void* out, int32_t layout, void* stream) {
+    if (!e || !out) return fail(AZ_ERR_ARG, "null argument");
+    if (layout != AZ_FEAT_F32_NCHW && layout != AZ_FEAT_BF16_NHWC) return fail(AZ_ERR_ARG, "bad layout");
+    DISPATCH_PPL(e, k_root_features, e->d.G, seen_bytes(e), stream, e->d, out, layout, (uint8_t*)nullptr);
+    return check_launch("k_root_features");
+}
+
+int az_rules_status(az_engine* e, double* score, int32_t* info, void* stream) {
+    if (!e) return fail(AZ_ERR_ARG, "null engine");
+    DISPATCH_PPL(e, k_status, e->d.G, seen_bytes(e), stream, e->d, score, info);
+    return check_launch("k_status");
+}
+
+int az_rules_export(az_engine* e, int8_t* board, int8_t* hist, int32_t* scalars, uint64_t* seen, void* stream) {
+    if (!e || !board || !hist || !scalars || !seen) return fail(AZ_ERR_ARG, "null argument");
+    hipLaunchKernelGGL(k_export, dim3(e->d.G), dim3(128), 0, (hipStream_t)stream, e->d, board, hist, scalars, seen);
+    return check_launch("k_export");
+}
+
+int az_rules_import(az_engine* e, const int8_t* board, const int8_t* hist, const int32_t* scalars, const uint64_t* seen,
+                    void* stream) {
+    if (!e || !board || !hist || !scalars || !seen) return fail(AZ_ERR_ARG, "null argument");
+    hipLaunchKernelGGL(k_import, dim3(e->d.G), dim3(128), 0, (hipStream_t)stream, e->d, board, hist, scalars, seen);
+    e->phase = PH_IDLE;
+    return check_launch("k_import");
+}
+
+int az_mcts_begin(az_engine* e, const uint8_t* enable, void* stream) {
+    if (!e) return fail(AZ_ERR_ARG, "null engine");
+    hipLaunchKernelGGL(k_begin, dim3((e->d.G + 63) / 64), dim3(64), 0, (hipStream_t)stream, e->d, enable);
+    hipLaunchKernelGGL(k_scan_rows, dim3(1), dim3(1024), 0, (hipStream_t)stream, e->d, 1);
+    e->phase = PH_ROOT;
+    e->sims_done = 0;
+    e->rows_known = false;
+    return check_launch("k_begin");
+}
+
+int az_mcts_select(az_engine* e, void* stream) {
+    if (!e) return fail(AZ_ERR_ARG, "null engine");
+    if (e->phase != PH_NEED_SELECT) return fail(AZ_ERR_STATE, "az_mcts_select: no batch to select (expand the pending rows first)");
+    e->batch_n = std::min(e->d.B, e->d.sims - e->sims_done);
+    DISPATCH_PPL(e, k_select, e->d.G, seen_bytes(e), stream, e->d, e->batch_n);
+    hipLaunchKernelGGL(k_scan_rows, dim3(1), dim3(1024), 0, (hipStream_t)stream, e->d, 0);
+    e->phase = PH_SELECTED;
+    e->rows_known = false;
+    return check_launch("k_select");
+}
+
+int az_mcts_pending(az_engine* e, int32_t* rows_out, void* stream) {
+    if (!e || !rows_out) return fail(AZ_ERR_ARG, "null argument");
+    if (e->phase != PH_ROOT && e->phase != PH_SELECTED) { *rows_out = 0; return AZ_OK; }
+    HIP_TRY(hipMemcpyAsync(e->ctl_host, e->d.ctl, 4 * sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    e->pending_rows = e->ctl_host[0];
+    e->rows_known = true;
+    *rows_out = e->pending_rows;
+    if (e->ctl_host[1] == AZ_ERR_NOCHILD) return fail(AZ_ERR_NOCHILD, "No child selected in MCTS");
+    if (e->ctl_host[1] == AZ_ERR_CAPACITY) return fail(AZ_ERR_CAPACITY, "search tree node capacity exceeded");
+    return AZ_OK;
+}
+
+static int need_rows(az_engine* e, void* stream) {
+    if (e->rows_known) return AZ_OK;
+    int32_t r;
+    return az_mcts_pending(e, &r, stream);
+}
+
+int az_mcts_gather(az_engine* e, void* out, int32_t layout, void* stream) {
+    if (!e || !out) return fail(AZ_ERR_ARG, "null argument");
+    if (e->phase != PH_ROOT && e->phase != PH_SELECTED) return fail(AZ_ERR_STATE, "az_mcts_gather: no pending rows");
+    if (layout != AZ_FEAT_F32_NCHW && layout != AZ_FEAT_BF16_NHWC) return fail(AZ_ERR_ARG, "bad layout");
+    int rc = need_rows(e, stream);
+    if (rc != AZ_OK) return rc;
+    if (e->pending_rows == 0) return AZ_OK;
+    const size_t shmem = seen_bytes(e) + (size_t)e->d.H * e->d.npad;
+    DISPATCH_PPL(e, k_leaf, e->pending_rows, shmem, stream, e->d, out, layout);
+    return check_launch("k_leaf");
+}
+
+int az_mcts_row_games(az_engine* e, int32_t* row_game, void* stream) {
+    if (!e || !row_game) return fail(AZ_ERR_ARG, "null argument");
+    int rc = need_rows(e, stream);
+    if (rc != AZ_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(row_game, e->d.row_game, (size_t)e->pending_rows * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return AZ_OK;
+}
+
+int az_mcts_expand(az_engine* e, const float* logits, const float* values, const double* noise, void* stream) {
+    if (!e) return fail(AZ_ERR_ARG, "null engine");
+    const size_t shmem = (size_t)e->d.A * 8 + 64;
+    if (e->phase == PH_ROOT) {
+        if (!logits) return fail(AZ_ERR_ARG, "null logits");
+        hipLaunchKernelGGL(k_expand_root, dim3(e->d.G), dim3(64), shmem, (hipStream_t)stream, e->d, logits, noise, e->last_priors);
+    } else if (e->phase == PH_SELECTED) {
+        int rc = need_rows(e, stream);
+        if (rc != AZ_OK) return rc;
+        if (e->pending_rows > 0 && (!logits || !values)) return fail(AZ_ERR_ARG, "null logits/values");
+        hipLaunchKernelGGL(k_expand_backup, dim3(e->d.G), dim3(64), shmem, (hipStream_t)stream, e->d, logits, values,
+                           e->batch_n, e->last_priors);
+        e->sims_done += e->batch_n;
+    } else {
+        return fail(AZ_ERR_STATE, "az_mcts_expand: nothing pending");
+    }
+    int rc = check_launch("k_expand");
+    if (rc != AZ_OK) return rc;
+    e->rows_known = false;
+    if (e->sims_done >= e->d.sims) { e->phase = PH_DONE; return 1; }
+    e->phase = PH_NEED_SELECT;
+    return 0;
+}
+
+int az_mcts_root_legal_counts(az_engine* e, int32_t* counts, void* stream) {
+    if (!e || !counts) return fail(AZ_ERR_ARG, "null argument");
+    if (e->phase != PH_ROOT) return fail(AZ_ERR_STATE, "root legal counts are available between gather and expand of the root rows");
+    hipLaunchKernelGGL(k_root_counts, dim3(e->d.G), dim3(64), 0, (hipStream_t)stream, e->d, counts);
+    return check_launch("k_root_counts");
+}
+
+int az_mcts_result(az_engine* e, int32_t* visits, double* root_value, void* stream) {
+    if (!e || !visits || !root_value) return fail(AZ_ERR_ARG, "null argument");
+    hipLaunchKernelGGL(k_result, dim3(e->d.G), dim3(64), 0, (hipStream_t)stream, e->d, visits, root_value);
+    return check_launch("k_result");
+}
+
+int az_mcts_last_priors(az_engine* e, double* priors, void* stream) {
+    if (!e || !priors) return fail(AZ_ERR_ARG, "null argument");
+    HIP_TRY(hipMemcpyAsync(priors, e->last_priors, (size_t)e->pending_rows * e->d.A * 8, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return AZ_OK;
+}
+
+int az_mcts_stats(az_engine* e, int64_t* out, void* stream) {
+    if (!e || !out) return fail(AZ_ERR_ARG, "null argument");
+    HIP_TRY(hipMemcpyAsync(e->stats_host, e->d.stats, 8 * sizeof(long long), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    for (int i = 0; i < 8; ++i) out[i] = e->stats_host[i];
+    return AZ_OK;
+}
+
+}  // extern "C"

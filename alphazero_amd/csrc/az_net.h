@@ -1,0 +1,34 @@
+// Shared declarations of the network code (parameter blob layout, bf16 MFMA path entry points).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <vector>
+
+#include "../../include/azamd.h"
+
+namespace az {
+
+struct BnOff { int64_t w, b, mean, var; };
+struct BlockOff { int64_t conv1; BnOff bn1; int64_t conv2; BnOff bn2; int64_t se_w1, se_b1, se_w2, se_b2; };
+// Offsets (in float32 words) into the flat parameter blob: the state_dict of model.py:61-87 in
+// registration order, every tensor flattened row-major, num_batches_tracked entries left out.
+struct NetLayout {
+    int64_t stem_w; BnOff stem_bn;
+    std::vector<BlockOff> blocks;
+    int64_t ph0_w; BnOff ph0_bn; int64_t ph3_w; BnOff ph3_bn; int64_t pfc_w, pfc_b;
+    int64_t vh0_w; BnOff vh0_bn; int64_t vh4_w, vh4_b, vh6_w, vh6_b;
+    int64_t total;
+};
+void net_layout(const az_net_config& c, NetLayout& L);
+void fold_bn(const float* P, int64_t w_off, const BnOff& bn, int cout, int64_t per_out, std::vector<float>& w,
+             std::vector<float>& b);
+
+// bf16 MFMA path (az_net_mfma.hip)
+struct MfmaNet;
+bool mfma_supported(const az_net_config& c);
+int mfma_create(const az_net_config& c, const NetLayout& L, const float* params, MfmaNet** out);
+void mfma_destroy(MfmaNet* m);
+int mfma_forward(MfmaNet* m, const void* feat_bf16_nhwc, int rows, float* logits, float* values, hipStream_t st);
+
+}  // namespace az

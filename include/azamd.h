@@ -1,0 +1,151 @@
+/*
+ * azamd.h -- C ABI of libazamd.so, the MI355X (gfx950) engine for the go_zero self-play hot path:
+ * Go rules + feature planes, batched PUCT search over device-resident trees for G lockstep games,
+ * and policy/value network inference.
+ *
+ * The upstream project is pure Python and has no FFI of its own; each entry point below names the
+ * upstream Python function (file:line under go_zero/) whose work it takes over. A Python binding
+ * (ctypes) that re-creates the upstream call surface on top of these functions ships in
+ * alphazero_amd/ and go_zero/.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative az_status; az_last_error() gives the text
+ *     for the calling thread;
+ *   - pointers named *_dev are device pointers owned by the caller, never freed or retained;
+ *   - `stream` is a hipStream_t passed as void*; work is enqueued asynchronously unless the
+ *     function is documented as synchronising;
+ *   - actions are r*n+c, pass = n*n; colours are BLACK=+1, WHITE=-1, EMPTY=0 (go.py:10-29);
+ *   - an engine is not thread-safe; use one engine per host thread / stream.
+ */
+#ifndef AZAMD_H
+#define AZAMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    AZ_OK = 0,
+    AZ_ERR_ARG = -1,      /* bad argument / unsupported size */
+    AZ_ERR_HIP = -2,      /* a HIP runtime call failed */
+    AZ_ERR_STATE = -3,    /* call made in the wrong phase of a search */
+    AZ_ERR_ILLEGAL = -4,  /* illegal move (go.py:179-180 ValueError) */
+    AZ_ERR_NOCHILD = -5,  /* "No child selected in MCTS" (mcts.py:114-115 RuntimeError) */
+    AZ_ERR_CAPACITY = -6  /* a per-game tree ran out of node slots */
+} az_status;
+
+typedef struct az_engine az_engine;
+typedef struct az_net az_net;
+
+/* Engine configuration. Mirrors GoState.new_game (go.py:62) and MCTS.__init__ (mcts.py:31-57). */
+typedef struct {
+    int32_t board_size;       /* n, 2..19 */
+    int32_t history_len;      /* H, 1..16 */
+    int32_t games;            /* G lockstep games held on the device */
+    int32_t simulations;      /* num_simulations */
+    int32_t inference_batch;  /* inference_batch_size (clamped to >= 1) */
+    int32_t topk_expand;      /* topk_expand (clamped to >= 0; 0 = expand every legal action) */
+    int32_t dedup_leaves;     /* 1: a leaf reached by several descents of one batch is evaluated once
+                                 (results are identical either way: the evaluator is a pure function) */
+    int32_t device;           /* HIP device ordinal */
+    double komi;
+    double c_base, c_init;    /* PUCT constants */
+    double dirichlet_eps;     /* root noise weight */
+    double virtual_loss;      /* clamped to >= 0 */
+} az_config;
+
+const char* az_last_error(void);
+/* 64-bit Zobrist key used for the situational-superko set; index = 2*point + (colour==WHITE) for
+ * stones, 2*361 + (to_play==WHITE) for the side to move. Same role as go.py:53-59 _state_hash. */
+uint64_t az_zobrist_key(int32_t index);
+
+int az_engine_create(const az_config* cfg, az_engine** out);
+int az_engine_destroy(az_engine* e);
+/* sizes a caller needs to allocate buffers */
+int az_engine_action_size(const az_engine* e);    /* A = n*n+1           (go.py:15-16)  */
+int az_engine_feature_planes(const az_engine* e); /* C = 2H+5            (go.py:32-34)  */
+int az_engine_seen_capacity(const az_engine* e);  /* entries per game in export/import  */
+int az_engine_max_rows(const az_engine* e);       /* upper bound on pending rows        */
+
+/* ---- rules on the G root states --------------------------------------------------------- */
+/* GoState.new_game (go.py:61-74) for the games with reset_mask_dev[g] != 0 (NULL = all). */
+int az_rules_reset(az_engine* e, const uint8_t* reset_mask_dev, void* stream);
+/* GoState.play (go.py:159-203) with actions_dev[g] (-1 = leave game g untouched). status_dev[g]
+ * receives 0, or AZ_ERR_ILLEGAL and the state is left unchanged. */
+int az_rules_play(az_engine* e, const int32_t* actions_dev, int32_t* status_dev, void* stream);
+/* legal_actions as a mask uint8 [G, A] (go.py:145-157; pass is always 1). */
+int az_rules_legal_mask(az_engine* e, uint8_t* mask_dev, void* stream);
+/* to_tensor (go.py:265-304). layout AZ_FEAT_F32_NCHW: float32 [G, C, n, n];
+ * AZ_FEAT_BF16_NHWC: bf16 [G, n*n, 32] (channels padded with zeros). */
+enum { AZ_FEAT_F32_NCHW = 0, AZ_FEAT_BF16_NHWC = 1 };
+int az_rules_features(az_engine* e, void* out_dev, int32_t layout, void* stream);
+/* score/winner/is_terminal (go.py:205-263): score_dev double [G,2] (black, white incl. komi),
+ * info_dev int32 [G,8] = to_play, consecutive_passes, move_count, black_captures, white_captures,
+ * last_move (-1 none), is_terminal, winner. Either pointer may be NULL. */
+int az_rules_status(az_engine* e, double* score_dev, int32_t* info_dev, void* stream);
+/* Whole-state export/import (device buffers): board int8 [G,n*n]; history int8 [G,H,n*n] newest
+ * first; scalars int32 [G,8] = to_play, passes, move_count, black_caps, white_caps, last_move,
+ * history_count, seen_count; seen uint64 [G, seen_capacity]. */
+int az_rules_export(az_engine* e, int8_t* board_dev, int8_t* hist_dev, int32_t* scalars_dev, uint64_t* seen_dev,
+                    void* stream);
+int az_rules_import(az_engine* e, const int8_t* board_dev, const int8_t* hist_dev, const int32_t* scalars_dev,
+                    const uint64_t* seen_dev, void* stream);
+
+/* ---- batched PUCT search (mcts.py:165-225 _run_single_root_search for every game) -------- */
+/* Start a search from the current root states. Games whose root is terminal, or with
+ * enable_mask_dev[g] == 0, sit the search out (mcts.py:234). Pending rows = the active roots. */
+int az_mcts_begin(az_engine* e, const uint8_t* enable_mask_dev, void* stream);
+/* Select phase of one batch (mcts.py:181-199): min(B, remaining) descents per game with virtual
+ * loss; pending rows = leaves to evaluate. */
+int az_mcts_select(az_engine* e, void* stream);
+/* Number of pending rows. Synchronises `stream`. Also reports and clears per-game failures
+ * (returns AZ_ERR_NOCHILD / AZ_ERR_CAPACITY). */
+int az_mcts_pending(az_engine* e, int32_t* rows_out, void* stream);
+/* Leaf gather: feature planes of the pending rows, dense, in row order (mcts.py:61). */
+int az_mcts_gather(az_engine* e, void* feat_out_dev, int32_t layout, void* stream);
+/* Row bookkeeping for callers that want it: game index int32 [rows] of each pending row. */
+int az_mcts_row_games(az_engine* e, int32_t* row_game_dev, void* stream);
+/* Expand + backup (mcts.py:66-91 masked softmax in float64, :118-163 expand with top-k, :205-218
+ * backup). logits_dev float32 [rows, A], values_dev float32 [rows]. After az_mcts_begin this expands
+ * the roots: noise_dev (double [G, A], Dirichlet sample of game g in its first n_legal entries, or
+ * NULL) is mixed into the root priors (mcts.py:121-124). Returns 1 when all simulations are done. */
+int az_mcts_expand(az_engine* e, const float* logits_dev, const float* values_dev, const double* noise_dev,
+                   void* stream);
+/* Number of legal actions of every root (host needs it to draw the Dirichlet sample). int32 [G]. */
+int az_mcts_root_legal_counts(az_engine* e, int32_t* counts_dev, void* stream);
+/* visits int32 [G, A] and root value double [G] (mcts.py:222-225). Inactive games give zeros. */
+int az_mcts_result(az_engine* e, int32_t* visits_dev, double* root_value_dev, void* stream);
+/* Priors of the pending rows' nodes after the last az_mcts_expand (double [rows, A], 0 where no
+ * child) -- for parity tests of the masked softmax. */
+int az_mcts_last_priors(az_engine* e, double* priors_dev, void* stream);
+/* Counters since az_mcts_begin: int64 [8] = simulations, rows evaluated, rows before dedup,
+ * sum of leaf depths, max depth, nodes allocated (max over games), terminal leaves, batches. Synchronises. */
+int az_mcts_stats(az_engine* e, int64_t* out8_host, void* stream);
+
+/* ---- policy/value network (model.py:43-97 AlphaZeroNet.forward, eval mode) ---------------- */
+typedef struct {
+    int32_t board_size, in_planes, channels, blocks, use_se, se_hidden, value_hidden;
+    int32_t precision; /* AZ_NET_BF16 or AZ_NET_F32 */
+    int32_t device;
+} az_net_config;
+enum { AZ_NET_BF16 = 0, AZ_NET_F32 = 1 };
+
+int az_net_create(const az_net_config* cfg, az_net** out);
+int az_net_destroy(az_net* net);
+/* Number of float32 words in the flat parameter blob and the offset of a named tensor in it. The
+ * blob is the state_dict (model.py:61-87) flattened in the order documented in az_net_param_layout. */
+int64_t az_net_param_count(const az_net* net);
+/* Upload weights: params_host is the flat float32 blob (host memory). BatchNorm running statistics
+ * are folded into the preceding convolution. Synchronises. */
+int az_net_load(az_net* net, const float* params_host, int64_t count);
+/* Forward pass for `rows` positions. feat_dev layout must match the precision (bf16 NHWC for
+ * AZ_NET_BF16, float32 NCHW for AZ_NET_F32). logits_dev float32 [rows, A], values_dev float32 [rows]. */
+int az_net_forward(az_net* net, const void* feat_dev, int32_t rows, float* logits_dev, float* values_dev,
+                   void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AZAMD_H */
