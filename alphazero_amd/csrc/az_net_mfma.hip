@@ -1,10 +1,618 @@
-// placeholder until the MFMA tower lands
-#include "az_net.h"
+// bf16 MFMA inference of the policy/value network (model.py:43-97, eval mode) for gfx950.
+//
+// k_tower: ONE launch runs the stem, every residual block (with squeeze-excite) and the two 1x1
+// head convolutions. A 512-thread workgroup owns TB whole boards (TB*n*n <= 256 positions, 3 boards
+// on 9x9); their activations stay in LDS ([position][channel] bf16) from the first layer to the last
+// and the residual stream stays in registers, so the only HBM/L2 traffic of the tower is the weight
+// stream. Each 3x3 convolution is an implicit GEMM: M = 256 positions, N = C output channels,
+// K = 9*C, computed with v_mfma_f32_32x32x16_bf16 by 8 waves (each wave a 64 x C/2 or 32 x C tile).
+// Board edges are handled by pointing out-of-board taps at a zero row in LDS. Weights are packed at
+// load time into the exact LDS image the B fragments are read from, tile after tile, and streamed
+// global -> registers -> LDS one K-tile ahead of the MFMAs.
+// The SE pooling is accumulated in 64-bit fixed point (order-independent), so the output of a
+// position does not depend on which other boards share its workgroup or launch.
+//
+// k_policy_tail / k_value_tail finish the heads (tiny next to the tower).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <algorithm>
 #include <string>
+#include <vector>
+
+#include "az_net.h"
+
 namespace az {
 int fail(int code, const std::string& msg);
-bool mfma_supported(const az_net_config&) { return false; }
-int mfma_create(const az_net_config&, const NetLayout&, const float*, MfmaNet**) { return fail(AZ_ERR_ARG, "bf16 path not built"); }
-void mfma_destroy(MfmaNet*) {}
-int mfma_forward(MfmaNet*, const void*, int, float*, float*, hipStream_t) { return fail(AZ_ERR_ARG, "bf16 path not built"); }
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+struct TowerParams {
+    int n, np, TB, rows, blocks, use_se, hid, cin_pad, q;
+    unsigned recip_np;           // floor(row / np) == (row * recip_np) >> 16 for row < 512
+    const uint16_t* feat;        // [rows][np][cin_pad] bf16
+    const uint4* w_stem;         // packed tiles
+    const float* b_stem;         // [C]
+    const uint4* w_tower;        // [blocks][2] packed convs
+    const float* b_tower;        // [blocks][2][C]
+    const float* se_w1;          // [blocks][hid][C]
+    const float* se_b1;          // [blocks][hid]
+    const float* se_w2;          // [blocks][C][hid]
+    const float* se_b2;          // [blocks][C]
+    const uint4* w_head;         // packed 1x1, NH columns (policy q | value q | zero pad)
+    const float* b_head;         // [NH]
+    uint16_t* hq;                // out: [rows][np][2q] bf16, relu(bn(conv1x1)) of both heads
+};
+
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
+    bf16x2 v = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(uint32_t, v);
 }
+__device__ __forceinline__ float bf16_lo(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+__device__ __forceinline__ uint16_t to_bf16(float a) {
+    __bf16 v = (__bf16)a;
+    return __builtin_bit_cast(uint16_t, v);
+}
+
+// Implicit-GEMM over `ntiles` K-tiles of KT channels each (tiles_per_tap tiles per 3x3 tap).
+// acc[mi][ni] += A(positions x K) * B(K x columns). A rows come from `act` (row stride in_stride
+// bytes, zero row at zrow); B tiles are streamed from `wg` through the two LDS buffers at bbuf.
+template <int MI, int NI, int KT, int NST>
+__device__ __forceinline__ void gemm_taps(f32x16 (&acc)[MI][NI], const uint4* __restrict__ wg, int ntiles, int tiles_per_tap,
+                                          int N, bool three, const char* act, int in_stride, const char* zrow, char* bbuf,
+                                          int n, const int (&ry)[MI], const int (&rx)[MI], const int (&rrow)[MI],
+                                          const bool (&rvalid)[MI], int tid, int lane, int col0) {
+    const int tile_bytes = KT * N * 2;
+    const int nvec = tile_bytes / 16;
+    const int h = lane >> 5, l31 = lane & 31;
+    for (int i = tid; i < nvec; i += 512) ((uint4*)bbuf)[i] = wg[i];
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const char* cur = bbuf + (t & 1) * tile_bytes;
+        uint4 stage[NST];
+        if (t + 1 < ntiles) {
+#pragma unroll
+            for (int s = 0; s < NST; ++s) {
+                const int idx = tid + 512 * s;
+                if (idx < nvec) stage[s] = wg[(size_t)(t + 1) * nvec + idx];
+            }
+        }
+        const int tap = t / tiles_per_tap, c0 = (t - tap * tiles_per_tap) * KT;
+        const int dy = three ? tap / 3 - 1 : 0, dx = three ? tap - (tap / 3) * 3 - 1 : 0;
+        const char* ap[MI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int yy = ry[mi] + dy, xx = rx[mi] + dx;
+            const bool ok = rvalid[mi] && yy >= 0 && yy < n && xx >= 0 && xx < n;
+            ap[mi] = (ok ? act + (rrow[mi] + dy * n + dx) * in_stride : zrow) + c0 * 2 + h * 16;
+        }
+        const char* bp = cur + ((size_t)h * N + col0 + l31) * 16;
+#pragma unroll
+        for (int ks = 0; ks < KT / 16; ++ks) {
+            bf16x8 a[MI], b[NI];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) a[mi] = *(const bf16x8*)(ap[mi] + ks * 32);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) b[ni] = *(const bf16x8*)(bp + ((size_t)ks * 2 * N + ni * 32) * 16);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+        }
+        if (t + 1 < ntiles) {
+            char* nxt = bbuf + ((t + 1) & 1) * tile_bytes;
+#pragma unroll
+            for (int s = 0; s < NST; ++s) {
+                const int idx = tid + 512 * s;
+                if (idx < nvec) ((uint4*)nxt)[idx] = stage[s];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int MI, int NI>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[MI][NI]) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+}
+
+// C channels; WM x WN waves (WM*WN == 8); NH = padded column count of the fused head 1x1 conv.
+template <int C, int WM, int WN, int NH>
+__global__ __launch_bounds__(512, 2) void k_tower(TowerParams P) {
+    constexpr int MI = 256 / (WM * 32), NI = C / (WN * 32), NIH = NH / (WN * 32);
+    constexpr int KT = C >= 64 ? 64 : 32;
+    constexpr int STRIDE = 2 * C + 16;
+    constexpr int NST = (KT * C * 2 / 16 + 511) / 512;
+    constexpr int NST_STEM = (32 * C * 2 / 16 + 511) / 512;
+    constexpr int NST_H = (KT * NH * 2 / 16 + 511) / 512;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* act = smem;
+    char* zrow = smem + 256 * STRIDE;
+    char* bbuf = zrow + ((STRIDE + 127) / 128) * 128;
+    float* scratch = (float*)bbuf;  // epilogue scratch shares the weight staging buffers
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int h = lane >> 5, l31 = lane & 31;
+    const int n = P.n, NP = P.np;
+    const int board0 = blockIdx.x * P.TB;
+    const int nb = min(P.TB, P.rows - board0);
+    const int vrows = nb * NP;  // valid rows of this workgroup
+
+    // ---- stage 0: zero row, feature tile -> act (row stride 2*cin_pad+16)
+    const int in_stride0 = 2 * P.cin_pad + 16;
+    for (int i = tid; i < STRIDE / 4; i += 512) ((uint32_t*)zrow)[i] = 0;
+    {
+        const int ppr = P.cin_pad * 2 / 16;  // 16-byte pieces per row
+        const uint4* src = (const uint4*)(P.feat + (size_t)board0 * NP * P.cin_pad);
+        for (int i = tid; i < 256 * ppr; i += 512) {
+            const int row = i / ppr, part = i - row * ppr;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (row < vrows) v = src[i];
+            *(uint4*)(act + row * in_stride0 + part * 16) = v;
+        }
+    }
+    // per-lane A-row geometry
+    int ry[MI], rx[MI], rrow[MI];
+    bool rvalid[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int row = wm * (32 * MI) + mi * 32 + l31;
+        const int b = (row * P.recip_np) >> 16, p = row - b * NP;
+        rrow[mi] = row;
+        ry[mi] = p / n;
+        rx[mi] = p - ry[mi] * n;
+        rvalid[mi] = row < vrows;
+    }
+    const int col0 = wn * (NI * 32);
+    const int row_base = wm * (32 * MI);
+    __syncthreads();
+
+    f32x16 acc[MI][NI];
+    uint32_t res[MI][NI][8];
+
+    // write relu(acc + bias) as bf16 into act; optionally keep it as the residual
+    auto store_act = [&](const float* bias, bool keep_res) {
+        __syncthreads();  // every wave has finished reading act
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int col = col0 + ni * 32 + l31;
+            const float bv = bias[col];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const int row = row_base + mi * 32 + 4 * h + (r & 3) + 8 * (r >> 2);
+                    const float v0 = fmaxf(acc[mi][ni][r] + bv, 0.f), v1 = fmaxf(acc[mi][ni][r + 1] + bv, 0.f);
+                    const uint32_t pk = pack_bf16(v0, v1);
+                    if (keep_res) res[mi][ni][r >> 1] = pk;
+                    *(uint16_t*)(act + row * STRIDE + col * 2) = (uint16_t)(pk & 0xffffu);
+                    *(uint16_t*)(act + (row + 1) * STRIDE + col * 2) = (uint16_t)(pk >> 16);
+                }
+            }
+        }
+        __syncthreads();
+    };
+
+    // ---- stem (model.py:61-65)
+    zero_acc<MI, NI>(acc);
+    gemm_taps<MI, NI, 32, NST_STEM>(acc, P.w_stem, 9 * (P.cin_pad / 32), P.cin_pad / 32, C, true, act, in_stride0, zrow, bbuf, n,
+                                    ry, rx, rrow, rvalid, tid, lane, col0);
+    store_act(P.b_stem, true);
+
+    // ---- residual tower (model.py:25-40)
+    const size_t conv_vecs = (size_t)9 * C * C * 2 / 16;
+    for (int blk = 0; blk < P.blocks; ++blk) {
+        zero_acc<MI, NI>(acc);
+        gemm_taps<MI, NI, KT, NST>(acc, P.w_tower + (size_t)(2 * blk) * conv_vecs, 9 * (C / KT), C / KT, C, true, act, STRIDE,
+                                   zrow, bbuf, n, ry, rx, rrow, rvalid, tid, lane, col0);
+        store_act(P.b_tower + (size_t)(2 * blk) * C, false);
+        zero_acc<MI, NI>(acc);
+        gemm_taps<MI, NI, KT, NST>(acc, P.w_tower + (size_t)(2 * blk + 1) * conv_vecs, 9 * (C / KT), C / KT, C, true, act, STRIDE,
+                                   zrow, bbuf, n, ry, rx, rrow, rvalid, tid, lane, col0);
+        const float* bias2 = P.b_tower + (size_t)(2 * blk + 1) * C;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const float bv = bias2[col0 + ni * 32 + l31];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] += bv;
+        }
+        if (P.use_se) {  // model.py:9-22, pooled per board in a fixed order
+            // Per-board channel sums are accumulated as 64-bit fixed point (2^-16 steps): integer
+            // addition is associative, so the pooled value of a board is bit-identical whichever
+            // slot of whichever workgroup it occupies.
+            long long* part = (long long*)scratch;             // [WM][TB][C]
+            float* pooled = (float*)(part + WM * P.TB * C);    // [TB][C]
+            float* hidden = pooled + P.TB * C;                 // [TB][hid]
+            float* sc = hidden + P.TB * P.hid;                 // [TB][C]
+            for (int b = 0; b < P.TB; ++b) {
+                long long s[NI];
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) s[ni] = 0;
+                const int lo = b * NP, hi = lo + NP;
+                if (b < nb && lo < row_base + 32 * MI && hi > row_base) {
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int row = row_base + mi * 32 + 4 * h + (r & 3) + 8 * (r >> 2);
+                            const bool in = row >= lo && row < hi;
+#pragma unroll
+                            for (int ni = 0; ni < NI; ++ni) s[ni] += in ? (long long)__float2int_rn(acc[mi][ni][r] * 65536.f) : 0ll;
+                        }
+                }
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    s[ni] += __shfl_xor(s[ni], 32);
+                    if (h == 0) part[(wm * P.TB + b) * C + col0 + ni * 32 + l31] = s[ni];
+                }
+            }
+            __syncthreads();
+            const float inv_np = 1.0f / (float)NP;
+            for (int i = tid; i < P.TB * C; i += 512) {
+                long long s = 0;
+#pragma unroll
+                for (int w = 0; w < WM; ++w) s += part[w * P.TB * C + i];
+                pooled[i] = (float)s * (1.0f / 65536.f) * inv_np;
+            }
+            __syncthreads();
+            {   // fc1 + relu: 8 lanes per output
+                const float* w1 = P.se_w1 + (size_t)blk * P.hid * C;
+                const float* b1 = P.se_b1 + (size_t)blk * P.hid;
+                const int sub = tid & 7;
+                for (int o = tid >> 3; o < P.TB * P.hid; o += 64) {
+                    const int b = o / P.hid, j = o - b * P.hid;
+                    float s = 0.f;
+                    for (int ch = sub; ch < C; ch += 8) s = fmaf(w1[j * C + ch], pooled[b * C + ch], s);
+                    s += __shfl_xor(s, 1);
+                    s += __shfl_xor(s, 2);
+                    s += __shfl_xor(s, 4);
+                    if (sub == 0) hidden[o] = fmaxf(s + b1[j], 0.f);
+                }
+            }
+            __syncthreads();
+            {   // fc2 + sigmoid
+                const float* w2 = P.se_w2 + (size_t)blk * C * P.hid;
+                const float* b2 = P.se_b2 + (size_t)blk * C;
+                for (int i = tid; i < P.TB * C; i += 512) {
+                    const int b = i / C, ch = i - b * C;
+                    float s = b2[ch];
+                    for (int j = 0; j < P.hid; ++j) s = fmaf(w2[ch * P.hid + j], hidden[b * P.hid + j], s);
+                    sc[i] = 1.f / (1.f + __expf(-s));
+                }
+            }
+            __syncthreads();
+            for (int b = 0; b < nb; ++b) {
+                const int lo = b * NP, hi = lo + NP;
+                if (lo >= row_base + 32 * MI || hi <= row_base) continue;
+                float sv[NI];
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) sv[ni] = sc[b * C + col0 + ni * 32 + l31];
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = row_base + mi * 32 + 4 * h + (r & 3) + 8 * (r >> 2);
+                        const bool in = row >= lo && row < hi;
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni) acc[mi][ni][r] = in ? acc[mi][ni][r] * sv[ni] : acc[mi][ni][r];
+                    }
+            }
+        }
+        // x = relu(y + x) (model.py:40); act <- bf16(x); residual stays in registers
+        __syncthreads();
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int col = col0 + ni * 32 + l31;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const int row = row_base + mi * 32 + 4 * h + (r & 3) + 8 * (r >> 2);
+                    const uint32_t old = res[mi][ni][r >> 1];
+                    const float v0 = fmaxf(acc[mi][ni][r] + bf16_lo(old), 0.f), v1 = fmaxf(acc[mi][ni][r + 1] + bf16_hi(old), 0.f);
+                    const uint32_t pk = pack_bf16(v0, v1);
+                    res[mi][ni][r >> 1] = pk;
+                    *(uint16_t*)(act + row * STRIDE + col * 2) = (uint16_t)(pk & 0xffffu);
+                    *(uint16_t*)(act + (row + 1) * STRIDE + col * 2) = (uint16_t)(pk >> 16);
+                }
+        }
+        __syncthreads();
+    }
+
+    // ---- both 1x1 head convolutions as one GEMM (model.py:68-71, :78-81)
+    {
+        f32x16 hacc[MI][NIH];
+        zero_acc<MI, NIH>(hacc);
+        const int hcol0 = wn * (NIH * 32);
+        gemm_taps<MI, NIH, KT, NST_H>(hacc, P.w_head, C / KT, C / KT, NH, false, act, STRIDE, zrow, bbuf, n, ry, rx, rrow, rvalid,
+                                      tid, lane, hcol0);
+        const int q2 = 2 * P.q;
+#pragma unroll
+        for (int ni = 0; ni < NIH; ++ni) {
+            const int col = hcol0 + ni * 32 + l31;
+            if (col >= q2) continue;
+            const float bv = P.b_head[col];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row_base + mi * 32 + 4 * h + (r & 3) + 8 * (r >> 2);
+                    if (row < vrows) P.hq[((size_t)board0 * NP + row) * q2 + col] = to_bf16(fmaxf(hacc[mi][ni][r] + bv, 0.f));
+                }
+        }
+    }
+}
+
+// Policy tail (model.py:72-76, :93-94): 1x1 conv q->2 + BN + ReLU, flatten channel-major, linear.
+__global__ __launch_bounds__(128) void k_policy_tail(const uint16_t* __restrict__ hq, const float* __restrict__ w3, const float* __restrict__ b3,
+                                                     const float* __restrict__ wfcT, const float* __restrict__ bfc, float* __restrict__ logits,
+                                                     int np, int q) {
+    extern __shared__ float flat[];  // [2*np]
+    const int r = blockIdx.x, A = np + 1, q2 = 2 * q;
+    for (int i = threadIdx.x; i < 2 * np; i += blockDim.x) {
+        const int c2 = i / np, pos = i - c2 * np;
+        const uint16_t* src = hq + ((size_t)r * np + pos) * q2;
+        float s = b3[c2];
+        for (int k = 0; k < q; ++k) s = fmaf(w3[c2 * q + k], __uint_as_float((uint32_t)src[k] << 16), s);
+        flat[i] = fmaxf(s, 0.f);
+    }
+    __syncthreads();
+    for (int a = threadIdx.x; a < A; a += blockDim.x) {
+        float s = bfc[a];
+        for (int i = 0; i < 2 * np; ++i) s = fmaf(wfcT[(size_t)i * A + a], flat[i], s);
+        logits[(size_t)r * A + a] = s;
+    }
+}
+
+// Value tail (model.py:82-86): flatten channel-major, linear + ReLU, linear + tanh. RB boards per block.
+template <int RB>
+__global__ __launch_bounds__(256) void k_value_tail(const uint16_t* __restrict__ hq, const uint16_t* __restrict__ w4T, const float* __restrict__ b4,
+                                                    const float* __restrict__ w6, const float* __restrict__ b6, float* __restrict__ values,
+                                                    int rows, int np, int q, int vh) {
+    extern __shared__ float v0[];  // [RB][q*np] then [RB][vh]
+    const int r0 = blockIdx.x * RB, nbk = min(RB, rows - r0), K = q * np, q2 = 2 * q;
+    float* hid = v0 + RB * K;
+    for (int i = threadIdx.x; i < RB * K; i += blockDim.x) {
+        const int b = i / K, k = i - b * K, ch = k / np, pos = k - ch * np;
+        v0[i] = b < nbk ? __uint_as_float((uint32_t)hq[((size_t)(r0 + b) * np + pos) * q2 + q + ch] << 16) : 0.f;
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < vh; j += blockDim.x) {
+        float acc[RB];
+#pragma unroll
+        for (int b = 0; b < RB; ++b) acc[b] = 0.f;
+        for (int k = 0; k < K; ++k) {
+            const float w = __uint_as_float((uint32_t)w4T[(size_t)k * vh + j] << 16);
+#pragma unroll
+            for (int b = 0; b < RB; ++b) acc[b] = fmaf(w, v0[b * K + k], acc[b]);
+        }
+#pragma unroll
+        for (int b = 0; b < RB; ++b) hid[b * vh + j] = fmaxf(acc[b] + b4[j], 0.f);
+    }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int b = wave; b < nbk; b += 4) {
+        float s = 0.f;
+        for (int j = lane; j < vh; j += 64) s = fmaf(w6[j], hid[b * vh + j], s);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) values[r0 + b] = tanhf(s + b6[0]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host
+struct MfmaNet {
+    az_net_config cfg;
+    int TB, cin_pad, NH, q;
+    std::vector<void*> allocs;
+    TowerParams P;
+    float *w3, *b3, *wfcT, *bfc, *b4, *w6, *b6;
+    uint16_t* w4T;
+    uint16_t* hq = nullptr;
+    int hq_rows = 0;
+};
+
+static uint16_t f2bf(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+// Pack folded weights w[cout][cin][taps] into the LDS B-fragment image, tile after tile:
+// [tile][kstep][half][column n][8 consecutive k], k = tap*cin_pad + ci.
+static std::vector<uint16_t> pack_conv(const std::vector<float>& w, int cout, int cin, int taps, int cin_pad, int ncols, int KT) {
+    const int K = taps * cin_pad;
+    std::vector<uint16_t> out((size_t)K * ncols, 0);
+    for (int k = 0; k < K; ++k) {
+        const int tap = k / cin_pad, ci = k % cin_pad, t = k / KT, kk = k % KT, ks = kk / 16, hh = (kk % 16) / 8, j = kk % 8;
+        if (ci >= cin) continue;
+        for (int nn = 0; nn < cout; ++nn)
+            out[(size_t)t * KT * ncols + (((size_t)ks * 2 + hh) * ncols + nn) * 8 + j] = f2bf(w[((size_t)nn * cin + ci) * taps + tap]);
+    }
+    return out;
+}
+
+template <typename T>
+static int up(MfmaNet* m, const std::vector<T>& v, T** out) {
+    void* p = nullptr;
+    if (hipMalloc(&p, std::max<size_t>(v.size(), 1) * sizeof(T)) != hipSuccess) return fail(AZ_ERR_HIP, "hipMalloc (network weights)");
+    m->allocs.push_back(p);
+    if (hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return fail(AZ_ERR_HIP, "hipMemcpy (network weights)");
+    *out = (T*)p;
+    return AZ_OK;
+}
+
+bool mfma_supported(const az_net_config& c) {
+    const bool cok = c.channels == 32 || c.channels == 64 || c.channels == 128 || c.channels == 192;
+    return cok && c.board_size <= 9 && c.board_size >= 2 && c.in_planes <= 64;
+}
+
+// LDS: activations, zero row, then a region shared by the two weight staging buffers and the
+// squeeze-excite scratch (int64 partials [WM][TB][C], pooled [TB][C], hidden [TB][hid], scale [TB][C]).
+static size_t tower_lds_bytes(int C, int NH, int TB, int hid) {
+    const int KT = C >= 64 ? 64 : 32, WM = C == 32 ? 8 : 4;
+    const size_t stride = 2 * C + 16;
+    const size_t tile = (size_t)KT * std::max(C, NH) * 2;
+    const size_t se = ((size_t)(2 * WM + 2) * TB * C + (size_t)TB * hid) * 4;
+    return 256 * stride + ((stride + 127) / 128) * 128 + std::max(2 * tile, se);
+}
+
+int mfma_create(const az_net_config& c, const NetLayout& L, const float* Pm, MfmaNet** out) {
+    if (!mfma_supported(c)) return fail(AZ_ERR_ARG, "bf16 MFMA path: unsupported network shape");
+    if (hipSetDevice(c.device) != hipSuccess) return fail(AZ_ERR_HIP, "hipSetDevice");
+    MfmaNet* m = new MfmaNet();
+    m->cfg = c;
+    const int C = c.channels, np = c.board_size * c.board_size, q = C / 4, A = np + 1;
+    m->TB = 256 / np;
+    m->cin_pad = c.in_planes <= 32 ? 32 : 64;
+    m->q = q;
+    m->NH = C == 192 ? 128 : (C == 32 ? 32 : 64);
+    const int KT = C >= 64 ? 64 : 32;
+    if (tower_lds_bytes(C, m->NH, m->TB, c.se_hidden) > 160 * 1024) { delete m; return fail(AZ_ERR_ARG, "bf16 MFMA path: LDS budget exceeded"); }
+    std::vector<float> w, b;
+    TowerParams& P = m->P;
+    memset(&P, 0, sizeof(P));
+    P.n = c.board_size; P.np = np; P.TB = m->TB; P.blocks = c.blocks; P.use_se = c.use_se; P.hid = c.se_hidden;
+    P.cin_pad = m->cin_pad; P.q = q;
+    P.recip_np = (65536 + np - 1) / np;
+    for (int row = 0; row < 512; ++row)
+        if (((unsigned)row * P.recip_np) >> 16 != (unsigned)(row / np)) { delete m; return fail(AZ_ERR_ARG, "reciprocal division check failed"); }
+    int rc;
+#define TRY(x) if ((rc = (x)) != AZ_OK) { mfma_destroy(m); return rc; }
+    {   // stem
+        fold_bn(Pm, L.stem_w, L.stem_bn, C, (int64_t)c.in_planes * 9, w, b);
+        std::vector<uint16_t> pk = pack_conv(w, C, c.in_planes, 9, m->cin_pad, C, 32);
+        uint16_t* d; float* bd;
+        TRY(up(m, pk, &d)); TRY(up(m, b, &bd));
+        P.w_stem = (const uint4*)d; P.b_stem = bd;
+    }
+    {   // tower
+        std::vector<uint16_t> all;
+        std::vector<float> ball, w1, b1, w2, b2;
+        for (int i = 0; i < c.blocks; ++i) {
+            const BlockOff& bo = L.blocks[i];
+            fold_bn(Pm, bo.conv1, bo.bn1, C, (int64_t)C * 9, w, b);
+            std::vector<uint16_t> pk = pack_conv(w, C, C, 9, C, C, KT);
+            all.insert(all.end(), pk.begin(), pk.end()); ball.insert(ball.end(), b.begin(), b.end());
+            fold_bn(Pm, bo.conv2, bo.bn2, C, (int64_t)C * 9, w, b);
+            pk = pack_conv(w, C, C, 9, C, C, KT);
+            all.insert(all.end(), pk.begin(), pk.end()); ball.insert(ball.end(), b.begin(), b.end());
+            if (c.use_se) {
+                w1.insert(w1.end(), Pm + bo.se_w1, Pm + bo.se_w1 + (int64_t)c.se_hidden * C);
+                b1.insert(b1.end(), Pm + bo.se_b1, Pm + bo.se_b1 + c.se_hidden);
+                w2.insert(w2.end(), Pm + bo.se_w2, Pm + bo.se_w2 + (int64_t)C * c.se_hidden);
+                b2.insert(b2.end(), Pm + bo.se_b2, Pm + bo.se_b2 + C);
+            }
+        }
+        uint16_t* d; float* f;
+        TRY(up(m, all, &d)); P.w_tower = (const uint4*)d;
+        TRY(up(m, ball, &f)); P.b_tower = f;
+        TRY(up(m, w1, &f)); P.se_w1 = f; TRY(up(m, b1, &f)); P.se_b1 = f;
+        TRY(up(m, w2, &f)); P.se_w2 = f; TRY(up(m, b2, &f)); P.se_b2 = f;
+    }
+    {   // fused head 1x1: columns [0,q) policy_head.0, [q,2q) value_head.0
+        std::vector<float> wp, bp, wv, bv, wh((size_t)2 * q * C), bh(m->NH, 0.f);
+        fold_bn(Pm, L.ph0_w, L.ph0_bn, q, C, wp, bp);
+        fold_bn(Pm, L.vh0_w, L.vh0_bn, q, C, wv, bv);
+        std::copy(wp.begin(), wp.end(), wh.begin());
+        std::copy(wv.begin(), wv.end(), wh.begin() + (size_t)q * C);
+        std::copy(bp.begin(), bp.end(), bh.begin());
+        std::copy(bv.begin(), bv.end(), bh.begin() + q);
+        std::vector<uint16_t> pk = pack_conv(wh, 2 * q, C, 1, C, m->NH, KT);
+        uint16_t* d; float* f;
+        TRY(up(m, pk, &d)); P.w_head = (const uint4*)d;
+        TRY(up(m, bh, &f)); P.b_head = f;
+    }
+    {   // tails
+        fold_bn(Pm, L.ph3_w, L.ph3_bn, 2, q, w, b);
+        TRY(up(m, w, &m->w3)); TRY(up(m, b, &m->b3));
+        std::vector<float> t((size_t)2 * np * A);
+        for (int a = 0; a < A; ++a)
+            for (int i = 0; i < 2 * np; ++i) t[(size_t)i * A + a] = Pm[L.pfc_w + (int64_t)a * 2 * np + i];
+        TRY(up(m, t, &m->wfcT));
+        TRY(up(m, std::vector<float>(Pm + L.pfc_b, Pm + L.pfc_b + A), &m->bfc));
+        const int vh = c.value_hidden, K = q * np;
+        std::vector<uint16_t> t4((size_t)K * vh);
+        for (int j = 0; j < vh; ++j)
+            for (int k = 0; k < K; ++k) t4[(size_t)k * vh + j] = f2bf(Pm[L.vh4_w + (int64_t)j * K + k]);
+        TRY(up(m, t4, &m->w4T));
+        TRY(up(m, std::vector<float>(Pm + L.vh4_b, Pm + L.vh4_b + vh), &m->b4));
+        TRY(up(m, std::vector<float>(Pm + L.vh6_w, Pm + L.vh6_w + vh), &m->w6));
+        TRY(up(m, std::vector<float>(Pm + L.vh6_b, Pm + L.vh6_b + 1), &m->b6));
+    }
+#undef TRY
+    // opt in to the large dynamic LDS size once
+    const size_t lds = tower_lds_bytes(C, m->NH, m->TB, c.se_hidden);
+    hipError_t e = hipSuccess;
+    switch (C) {
+        case 32: e = hipFuncSetAttribute((const void*)k_tower<32, 8, 1, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); break;
+        case 64: e = hipFuncSetAttribute((const void*)k_tower<64, 4, 2, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); break;
+        case 128: e = hipFuncSetAttribute((const void*)k_tower<128, 4, 2, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); break;
+        case 192: e = hipFuncSetAttribute((const void*)k_tower<192, 4, 2, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); break;
+    }
+    if (e != hipSuccess) { mfma_destroy(m); return fail(AZ_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); }
+    const size_t vt = ((size_t)4 * q * np + 4 * c.value_hidden) * 4;
+    e = hipFuncSetAttribute((const void*)k_value_tail<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vt);
+    if (e != hipSuccess) { mfma_destroy(m); return fail(AZ_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); }
+    *out = m;
+    return AZ_OK;
+}
+
+void mfma_destroy(MfmaNet* m) {
+    if (!m) return;
+    (void)hipSetDevice(m->cfg.device);
+    (void)hipDeviceSynchronize();
+    for (void* p : m->allocs) (void)hipFree(p);
+    if (m->hq) (void)hipFree(m->hq);
+    delete m;
+}
+
+int mfma_forward(MfmaNet* m, const void* feat, int rows, float* logits, float* values, hipStream_t st) {
+    const az_net_config& c = m->cfg;
+    const int C = c.channels, np = c.board_size * c.board_size, q = m->q;
+    if (rows > m->hq_rows) {  // scratch for the head activations grows outside the steady state
+        if (hipDeviceSynchronize() != hipSuccess) return fail(AZ_ERR_HIP, "hipDeviceSynchronize");
+        if (m->hq) (void)hipFree(m->hq);
+        m->hq = nullptr;
+        const int cap = rows + rows / 4 + 16;
+        if (hipMalloc((void**)&m->hq, (size_t)cap * np * 2 * q * 2) != hipSuccess) return fail(AZ_ERR_HIP, "hipMalloc (head scratch)");
+        m->hq_rows = cap;
+    }
+    TowerParams P = m->P;
+    P.rows = rows;
+    P.feat = (const uint16_t*)feat;
+    P.hq = m->hq;
+    const int grid = (rows + m->TB - 1) / m->TB;
+    const size_t lds = tower_lds_bytes(C, m->NH, m->TB, c.se_hidden);
+    switch (C) {
+        case 32: hipLaunchKernelGGL((k_tower<32, 8, 1, 32>), dim3(grid), dim3(512), lds, st, P); break;
+        case 64: hipLaunchKernelGGL((k_tower<64, 4, 2, 64>), dim3(grid), dim3(512), lds, st, P); break;
+        case 128: hipLaunchKernelGGL((k_tower<128, 4, 2, 64>), dim3(grid), dim3(512), lds, st, P); break;
+        case 192: hipLaunchKernelGGL((k_tower<192, 4, 2, 128>), dim3(grid), dim3(512), lds, st, P); break;
+        default: return fail(AZ_ERR_ARG, "unsupported channel count");
+    }
+    hipLaunchKernelGGL(k_policy_tail, dim3(rows), dim3(128), (size_t)2 * np * 4, st, m->hq, m->w3, m->b3, m->wfcT, m->bfc, logits, np, q);
+    const size_t vt = ((size_t)4 * q * np + 4 * c.value_hidden) * 4;
+    hipLaunchKernelGGL((k_value_tail<4>), dim3((rows + 3) / 4), dim3(256), vt, st, m->hq, m->w4T, m->b4, m->w6, m->b6, values, rows, np, q,
+                       c.value_hidden);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return fail(AZ_ERR_HIP, std::string("bf16 forward: ") + hipGetErrorString(err));
+    return AZ_OK;
+}
+
+}  // namespace az

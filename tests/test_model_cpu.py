@@ -1,0 +1,39 @@
+"""Host-side torch module: state_dict contract and outputs against golden vectors from the upstream
+AlphaZeroNet (model.py) with seed-generated weights."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+import golden_io
+import stubnets
+from alphazero_amd.model import AlphaZeroNet, PolicyValueNet
+from tests_common import build_golden_net, GOLDEN_NETS
+
+
+def test_alias():
+    assert PolicyValueNet is AlphaZeroNet
+
+
+@pytest.mark.parametrize("name", GOLDEN_NETS)
+def test_state_dict_contract_and_outputs(name):
+    z = golden_io.load("network")
+    net, x, kw = build_golden_net(name)
+    shapes = json.loads(bytes(z[f"{name}/shapes_json"]).decode())
+    sd = net.state_dict()
+    assert [[k, list(v.shape)] for k, v in sd.items()] == shapes        # same keys, order and shapes
+    assert sum(p.numel() for p in net.parameters()) == int(z[f"{name}/nparams"][0])
+    assert net.board_size == kw["board_size"] and net.action_dim == kw["board_size"] ** 2 + 1
+    with torch.inference_mode():
+        lg, v = net(torch.from_numpy(x))
+    assert np.abs(lg.numpy() - z[f"{name}/logits"]).max() < 2e-5
+    assert np.abs(v.numpy() - z[f"{name}/value"]).max() < 2e-5
+
+
+def test_flat_parameter_blob_length():
+    net, _, _ = build_golden_net("n5_c32_b1")
+    blob = net.flat_parameters()
+    assert blob.dtype == np.float32
+    n_bn = sum(1 for k in net.state_dict() if k.endswith("num_batches_tracked"))
+    assert blob.size == sum(v.numel() for v in net.state_dict().values()) - n_bn

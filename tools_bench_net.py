@@ -1,0 +1,33 @@
+"""Micro-benchmark of the bf16 network forward (rows positions) with HIP events."""
+import sys, time
+import torch
+sys.path.insert(0, "tests")
+from alphazero_amd.model import AlphaZeroNet
+
+def main():
+    rows = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+    ch = int(sys.argv[2]) if len(sys.argv) > 2 else 192
+    blocks = int(sys.argv[3]) if len(sys.argv) > 3 else 12
+    torch.manual_seed(0)
+    net = AlphaZeroNet(channels=ch, num_blocks=blocks).eval().to("cuda:0")
+    nn = net.native("bf16")
+    f = (torch.rand((rows, 81, 32), device="cuda:0") < 0.3).to(torch.bfloat16)
+    f[:, :, 21:] = 0
+    for _ in range(3):
+        nn(f)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    iters = 10
+    e0.record()
+    for _ in range(iters):
+        nn(f)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    macs = {(192, 12): 650.5e6, (64, 4): 25.4e6}.get((ch, blocks))
+    if macs is None:
+        macs = 81 * 9 * 21 * ch + blocks * 2 * 81 * 9 * ch * ch
+    fl = 2 * macs * rows
+    print(f"rows={rows} ch={ch} blocks={blocks}: {ms:.3f} ms/forward, {rows/ms*1e3:.0f} pos/s, {fl/ms/1e9:.1f} TFLOP/s")
+
+main()
