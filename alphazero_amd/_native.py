@@ -60,6 +60,12 @@ SIGNATURES = {
     "az_net_param_count": (_I64, [_VP]),
     "az_net_load": (_I32, [_VP, _VP, _I64]),
     "az_net_forward": (_I32, [_VP, _VP, _I32, _VP, _VP, _VP]),
+    "az_net_profile": (_I32, [_VP, _I32, C.POINTER(C.c_double), C.POINTER(_I64), C.POINTER(_I64)]),
+    "az_rng_create": (_I32, [_I32, C.POINTER(_VP)]),
+    "az_rng_destroy": (_I32, [_VP]),
+    "az_rng_seed": (_I32, [_VP, _I32, C.c_uint32]),
+    "az_rng_dirichlet": (_I32, [_VP, _VP, C.c_double, _VP, _I32, _I32]),
+    "az_rng_random_sample": (_I32, [_VP, _VP, _VP]),
 }
 
 _lib = None

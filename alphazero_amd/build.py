@@ -6,7 +6,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = ["az_engine.hip", "az_net.hip", "az_net_mfma.hip"]
+SRC = ["az_engine.hip", "az_net.hip", "az_net_mfma.hip", "az_hostrng.cpp"]
 HDR = ["az_board.cuh", "az_net.h", "../../include/azamd.h"]
 # -ffp-contract=off: the search kernels must round every float64 product and sum separately.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
@@ -21,19 +21,20 @@ def build(force: bool = False, verbose: bool = False) -> str:
     objs = []
     procs = []
     for s in SRC:
-        o = os.path.join(csrc, s.replace(".hip", ".o"))
+        o = os.path.join(csrc, os.path.splitext(s)[0] + ".o")
         objs.append(o)
         src = os.path.join(csrc, s)
         if not force and os.path.exists(o) and all(os.path.getmtime(o) >= os.path.getmtime(d) for d in [src] + deps[len(SRC):]):
             continue
-        cmd = ["hipcc", *FLAGS, "-c", src, "-o", o]
+        cmd = ["hipcc", *FLAGS, "-c", src, "-o", o] if s.endswith(".hip") else \
+              ["hipcc", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-c", src, "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((s, subprocess.Popen(cmd)))
     for s, p in procs:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {s}")
-    cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *objs]
+    cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", out, *objs]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -29,6 +29,8 @@ struct MfmaNet;
 bool mfma_supported(const az_net_config& c);
 int mfma_create(const az_net_config& c, const NetLayout& L, const float* params, MfmaNet** out);
 void mfma_destroy(MfmaNet* m);
+void mfma_set_profiling(MfmaNet* m, bool on);
+int mfma_profile(MfmaNet* m, double* tower_ms, long long* launches, long long* rows);
 int mfma_forward(MfmaNet* m, const void* feat_bf16_nhwc, int rows, float* logits, float* values, hipStream_t st);
 
 }  // namespace az

@@ -274,6 +274,20 @@ static int ensure_scratch(az_net* net, int rows) {
     return AZ_OK;
 }
 
+int az_net_profile(az_net* net, int32_t enable, double* tower_ms, int64_t* launches, int64_t* rows) {
+    if (!net) return fail(AZ_ERR_ARG, "null network");
+    if (net->cfg.precision != AZ_NET_BF16 || !net->mfma) return fail(AZ_ERR_STATE, "az_net_profile: bf16 network not loaded");
+    if (tower_ms && launches && rows) {
+        long long l = 0, r = 0;
+        int rc = mfma_profile(net->mfma, tower_ms, &l, &r);
+        if (rc != AZ_OK) return rc;
+        *launches = l;
+        *rows = r;
+    }
+    mfma_set_profiling(net->mfma, enable != 0);
+    return AZ_OK;
+}
+
 int az_net_forward(az_net* net, const void* feat, int32_t rows, float* logits, float* values, void* stream_) {
     if (!net || !feat || !logits || !values) return fail(AZ_ERR_ARG, "null argument");
     if (!net->loaded) return fail(AZ_ERR_STATE, "az_net_forward before az_net_load");

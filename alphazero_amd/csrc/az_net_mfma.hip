@@ -424,6 +424,11 @@ struct MfmaNet {
     uint16_t* w4T;
     uint16_t* hq = nullptr;
     int hq_rows = 0;
+    // optional timing of the tower kernel with HIP events on the launch stream
+    bool profiling = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    size_t ev_used = 0;
+    long long prof_rows = 0;
 };
 
 static uint16_t f2bf(float f) {
@@ -573,10 +578,33 @@ int mfma_create(const az_net_config& c, const NetLayout& L, const float* Pm, Mfm
     return AZ_OK;
 }
 
+void mfma_set_profiling(MfmaNet* m, bool on) {
+    m->profiling = on;
+    m->ev_used = 0;
+    m->prof_rows = 0;
+}
+
+int mfma_profile(MfmaNet* m, double* tower_ms, long long* launches, long long* rows) {
+    double total = 0.0;
+    for (size_t i = 0; i < m->ev_used; ++i) {
+        if (hipEventSynchronize(m->events[i].second) != hipSuccess) return fail(AZ_ERR_HIP, "hipEventSynchronize");
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, m->events[i].first, m->events[i].second) != hipSuccess) return fail(AZ_ERR_HIP, "hipEventElapsedTime");
+        total += ms;
+    }
+    *tower_ms = total;
+    *launches = (long long)m->ev_used;
+    *rows = m->prof_rows;
+    m->ev_used = 0;
+    m->prof_rows = 0;
+    return AZ_OK;
+}
+
 void mfma_destroy(MfmaNet* m) {
     if (!m) return;
     (void)hipSetDevice(m->cfg.device);
     (void)hipDeviceSynchronize();
+    for (auto& e : m->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     for (void* p : m->allocs) (void)hipFree(p);
     if (m->hq) (void)hipFree(m->hq);
     delete m;
@@ -599,6 +627,17 @@ int mfma_forward(MfmaNet* m, const void* feat, int rows, float* logits, float* v
     P.hq = m->hq;
     const int grid = (rows + m->TB - 1) / m->TB;
     const size_t lds = tower_lds_bytes(C, m->NH, m->TB, c.se_hidden);
+    std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
+    if (m->profiling) {
+        if (m->ev_used == m->events.size()) {
+            hipEvent_t a, b;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return fail(AZ_ERR_HIP, "hipEventCreate");
+            m->events.emplace_back(a, b);
+        }
+        ev = &m->events[m->ev_used++];
+        m->prof_rows += rows;
+        (void)hipEventRecord(ev->first, st);
+    }
     switch (C) {
         case 32: hipLaunchKernelGGL((k_tower<32, 8, 1, 32>), dim3(grid), dim3(512), lds, st, P); break;
         case 64: hipLaunchKernelGGL((k_tower<64, 4, 2, 64>), dim3(grid), dim3(512), lds, st, P); break;
@@ -606,6 +645,7 @@ int mfma_forward(MfmaNet* m, const void* feat, int rows, float* logits, float* v
         case 192: hipLaunchKernelGGL((k_tower<192, 4, 2, 128>), dim3(grid), dim3(512), lds, st, P); break;
         default: return fail(AZ_ERR_ARG, "unsupported channel count");
     }
+    if (ev) (void)hipEventRecord(ev->second, st);
     hipLaunchKernelGGL(k_policy_tail, dim3(rows), dim3(128), (size_t)2 * np * 4, st, m->hq, m->w3, m->b3, m->wfcT, m->bfc, logits, np, q);
     const size_t vt = ((size_t)4 * q * np + 4 * c.value_hidden) * 4;
     hipLaunchKernelGGL((k_value_tail<4>), dim3((rows + 3) / 4), dim3(256), vt, st, m->hq, m->w4T, m->b4, m->w6, m->b6, values, rows, np, q,

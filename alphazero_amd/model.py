@@ -164,3 +164,13 @@ class NativeNet:
         return logits, values
 
     __call__ = forward
+
+    def profile(self, enable: bool, read: bool = False):
+        """Switch HIP-event timing of the tower kernel on/off; with read=True first return
+        (total_ms, launches, rows) accumulated since it was enabled."""
+        if read:
+            ms, ln, rw = C.c_double(), C.c_int64(), C.c_int64()
+            N.check(self.L.az_net_profile(self._h, 1 if enable else 0, C.byref(ms), C.byref(ln), C.byref(rw)), "az_net_profile")
+            return ms.value, ln.value, rw.value
+        N.check(self.L.az_net_profile(self._h, 1 if enable else 0, None, None, None), "az_net_profile")
+        return None

@@ -145,6 +145,28 @@ int az_net_load(az_net* net, const float* params_host, int64_t count);
 int az_net_forward(az_net* net, const void* feat_dev, int32_t rows, float* logits_dev, float* values_dev,
                    void* stream);
 
+/* Timing of the dominant kernel (the fused tower) with HIP events recorded on the launch stream.
+ * If the three output pointers are non-NULL they receive the total milliseconds, launch count and
+ * row count accumulated since profiling was last enabled (synchronises on the recorded events);
+ * then profiling is switched on (enable != 0) or off with the counters cleared. bf16 path only.
+ * No upstream counterpart: measurement aid for bench.py. */
+int az_net_profile(az_net* net, int32_t enable, double* tower_ms, int64_t* launches, int64_t* rows);
+
+/* ---- host-side random streams (no device work) ------------------------------------------------ */
+/* One legacy-NumPy-compatible MT19937 stream per game. The upstream code draws from the global
+ * np.random state: np.random.dirichlet([alpha]*k) for the root noise (mcts.py:122) and the uniform
+ * behind np.random.choice(len(pi), p=pi) (mcts.py:281). With one stream per game, game g in a
+ * lockstep batch draws what a sequential upstream run seeded with np.random.seed(seed_g) draws. */
+typedef struct az_rng az_rng;
+int az_rng_create(int32_t count, az_rng** out);
+int az_rng_destroy(az_rng* r);
+int az_rng_seed(az_rng* r, int32_t index, uint32_t seed);
+/* out (host, double [count, stride]) gets dirichlet([alpha]*counts[g]) in its first counts[g] entries. */
+int az_rng_dirichlet(az_rng* r, const int32_t* counts_host, double alpha, double* out_host, int32_t stride,
+                     int32_t threads);
+/* One uniform double in [0,1) per stream with mask_host[g] != 0 (NULL = all): RandomState.random_sample(). */
+int az_rng_random_sample(az_rng* r, const uint8_t* mask_host, double* out_host);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,118 @@
+"""The upstream call surface (go_zero.GoState / MCTS / self-play loop) served by the device engine,
+checked against golden vectors recorded from the upstream Python code."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+import golden_io
+import stubnets
+from gpu_util import stub_evaluator
+
+pytestmark = pytest.mark.gpu
+
+
+def test_gostate_facade_replays_golden_games():
+    from go_zero import GoState, decode_action
+    picks = [("rules_scripted", "ko"), ("rules_scripted", "suicide"), ("rules_scripted", "tie_komi_int"),
+             ("rules_scripted", "hist1_7x7"), ("rules_5x5", "g1"), ("rules_9x9", "g0")]
+    for pack, name in picks:
+        rec = golden_io.games(pack)[name]
+        n, hist = (int(x) for x in rec["cfg"])
+        st = GoState.new_game(board_size=n, komi=float(rec["komi"][0]), history_len=hist)
+        states = [st]
+        for ply, a in enumerate(list(rec["actions"]) + [None]):
+            m = rec["meta"][ply]
+            assert np.array_equal(st.board.reshape(-1), rec["boards"][ply])
+            assert (st.to_play, st.consecutive_passes, st.move_count, st.black_captures, st.white_captures) == tuple(m[:5])
+            assert (-1 if st.last_move is None else st.last_move[0] * n + st.last_move[1]) == m[5]
+            assert st.is_terminal() == bool(m[6]) and st.winner() == m[7]
+            assert len(st.board_history) == m[8] and len(st.seen_hashes) == m[9]
+            legal = golden_io.unpack_legal(rec["legal"][ply], n)
+            assert st.legal_actions() == [int(x) for x in np.nonzero(legal)[0]]
+            assert np.array_equal(np.array(st.score()), rec["scores"][ply])
+            t = st.to_tensor()
+            assert t.dtype == np.float32 and t.shape == (2 * hist + 5, n, n)
+            assert np.array_equal((t[: 2 * hist + 3] > 0.5).astype(np.uint8), golden_io.unpack_planes(rec["planes"][ply], hist, n))
+            if a is not None:
+                st = st.play(decode_action(n, int(a)))
+                states.append(st)
+        # value semantics: earlier states are untouched by later plays
+        assert np.array_equal(states[0].board, np.zeros((n, n), np.int8)) and states[0].move_count == 0
+
+
+def test_gostate_illegal_move_raises_valueerror():
+    from go_zero import GoState
+    st = GoState.new_game(5).play((2, 2))
+    with pytest.raises(ValueError, match="Illegal move"):
+        st.play((2, 2))
+    assert not st.is_legal((2, 2)) and st.is_legal(None) and not st.is_legal((7, 0))
+
+
+class _Stub:
+    """model(x) -> (logits, value) like a torch module, on whatever device x lives."""
+
+    def __init__(self, kind):
+        self.kind = kind
+
+    def __call__(self, x):
+        lg, v = stubnets.stub_eval(self.kind, x.detach().cpu().numpy())
+        return torch.from_numpy(lg).to(x.device), torch.from_numpy(v).to(x.device)
+
+
+CASES = [c for c in golden_io.search_cases() if c["name"] in
+         ("grid3_uniform_B4_K48", "grid10_hash_B4_K0", "grid15_hash_B16_K48", "cfg3_open", "cfg3_late", "one_pass_root",
+          "five_smoke", "five_late", "thirteen_h4", "grid21_sharp_B8_K48")]
+
+
+@pytest.mark.parametrize("c", CASES, ids=[c["name"] for c in CASES])
+def test_mcts_run_matches_upstream(c):
+    from go_zero import GoState, MCTS, decode_action
+    st = GoState.new_game(board_size=c["n"], komi=c["komi"], history_len=c["hist"])
+    for a in c["root_actions"]:
+        st = st.play(decode_action(c["n"], int(a)))
+    m = MCTS(_Stub(c["kind"]), board_size=c["n"], num_simulations=c["sims"], inference_batch_size=c["B"],
+             topk_expand=c["K"], virtual_loss=c["VL"], device="cpu")
+    np.random.seed(c["rseed"])
+    pi, action, rv = m.run(st, temperature=c["T"], add_exploration_noise=c["noise"], return_root_value=True)
+    assert pi.dtype == np.float32 and pi.tobytes() == c["pi"].tobytes()
+    assert action == c["action"] and rv == c["root_value"]
+    np.random.seed(c["rseed"])
+    out = m.run(st, temperature=c["T"], add_exploration_noise=c["noise"])
+    assert len(out) == 2 and out[1] == c["action"]
+
+
+def test_mcts_terminal_root():
+    from go_zero import GoState, MCTS
+    st = GoState.new_game(5).play(None).play(None)
+    pi, a, v = MCTS(_Stub("hash"), board_size=5, num_simulations=4).run(st, return_root_value=True)
+    assert a == 25 and pi[-1] == 1.0 and v == st.outcome_for_current_player()
+
+
+@pytest.mark.parametrize("name", ["game_hash", "game_topk", "game_resign"])
+@pytest.mark.parametrize("slots", [1, 3])
+def test_lockstep_selfplay_reproduces_upstream_game(name, slots):
+    """Game 0 of a lockstep run seeded like the upstream run must equal the upstream trajectory,
+    whatever else shares the batch."""
+    from alphazero_amd.selfplay import BatchedSelfPlay, SelfPlayConfig
+    z = golden_io.load("selfplay")
+    kw = json.loads(bytes(z[f"{name}/cfg_json"]).decode())
+    kind = bytes(z[f"{name}/kind"]).decode()
+    cfg = SelfPlayConfig(board_size=5, **kw)
+    sp = BatchedSelfPlay(stub_evaluator(kind), cfg, games=slots, seed0=321)
+    samples, bw, ww, dd = sp.run(num_games=slots)
+    assert bw + ww + dd == slots
+    traj, winner = sp.finished[0]
+    assert winner == int(z[f"{name}/winner"][0])
+    assert len(traj) == len(z[f"{name}/pi"])
+    want_actions = z[f"{name}/actions"]
+    for i, (packed, capf, pi, player, difficulty) in enumerate(traj):
+        assert pi.tobytes() == z[f"{name}/pi"][i].tobytes(), f"pi at move {i}"
+        assert np.array_equal(packed, z[f"{name}/planes"][i]), f"planes at move {i}"
+    n0 = len(traj)
+    got = samples[:n0]
+    assert np.array_equal(np.array([s[2] for s in got]), z[f"{name}/z"])
+    assert np.array_equal(np.array([s[3] for s in got]), z[f"{name}/difficulty"])
+    assert got[0][0].shape == (21, 5, 5) and got[0][0].dtype == np.float32
+    del want_actions
