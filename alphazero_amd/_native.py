@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libazamd.so")
+# AZAMD_LIB selects another build of the same library (e.g. a diagnostic build with in-kernel stamps)
+LIB_PATH = os.environ.get("AZAMD_LIB") or os.path.join(_HERE, "libazamd.so")
 
 AZ_OK, AZ_ERR_ARG, AZ_ERR_HIP, AZ_ERR_STATE, AZ_ERR_ILLEGAL, AZ_ERR_NOCHILD, AZ_ERR_CAPACITY = 0, -1, -2, -3, -4, -5, -6
 AZ_FEAT_F32_NCHW, AZ_FEAT_BF16_NHWC = 0, 1

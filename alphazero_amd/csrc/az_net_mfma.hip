@@ -8,14 +8,15 @@
 // K = 9*C, computed with v_mfma_f32_32x32x16_bf16 by 8 waves (each wave a 64 x C/2 or 32 x C tile).
 // Board edges are handled by pointing out-of-board taps at a zero row in LDS. Weights are packed at
 // load time into the exact LDS image the B fragments are read from, tile after tile, and streamed
-// global -> registers -> LDS one K-tile ahead of the MFMAs.
-// The SE pooling is accumulated in 64-bit fixed point (order-independent), so the output of a
-// position does not depend on which other boards share its workgroup or launch.
+// global -> LDS (global_load_lds, no staging registers) one K-tile ahead of the MFMAs.
+// The SE pooling adds a board's positions in index order (one thread per board and channel), so the
+// output of a position does not depend on which other boards share its workgroup or launch.
 //
 // k_policy_tail / k_value_tail finish the heads (tiny next to the tower).
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <string.h>
 
 #include <algorithm>
@@ -39,14 +40,27 @@ struct TowerParams {
     const float* b_stem;         // [C]
     const uint4* w_tower;        // [blocks][2] packed convs
     const float* b_tower;        // [blocks][2][C]
-    const float* se_w1;          // [blocks][hid][C]
-    const float* se_b1;          // [blocks][hid]
-    const float* se_w2;          // [blocks][C][hid]
-    const float* se_b2;          // [blocks][C]
+    const uint4* se_blob;        // [blocks] packed {w1 bf16 [hid][C], w2^T bf16 [hid][C], b1 f32 [hid], b2 f32 [C]}, padded to 1 KiB
+    int se_vecs;                 // 16-byte vectors per block in se_blob (multiple of 64)
     const uint4* w_head;         // packed 1x1, NH columns (policy q | value q | zero pad)
     const float* b_head;         // [NH]
     uint16_t* hq;                // out: [rows][np][2q] bf16, relu(bn(conv1x1)) of both heads
+    unsigned long long* stamps;  // diagnostic build (-DAZ_STAMP) only: per-workgroup phase cycle sums
 };
+
+#ifdef AZ_STAMP
+#define STAMP(slot)                                                                    \
+    do {                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                             \
+        unsigned long long t_;                                                         \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");     \
+        __builtin_amdgcn_sched_barrier(0);                                             \
+        stamp_acc[slot] += t_ - stamp_last;                                            \
+        stamp_last = t_;                                                               \
+    } while (0)
+#else
+#define STAMP(slot) do {} while (0)
+#endif
 
 __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
     bf16x2 v = {(__bf16)a, (__bf16)b};
@@ -59,29 +73,34 @@ __device__ __forceinline__ uint16_t to_bf16(float a) {
     return __builtin_bit_cast(uint16_t, v);
 }
 
+// Asynchronous global -> LDS copy of one packed weight tile (nvec 16-byte vectors, a multiple of 64):
+// every wave-instruction moves 1 KiB (64 lanes x 16 B) straight into LDS, no staging registers.
+__device__ __forceinline__ void stage_tile(const uint4* __restrict__ src, char* dst, int nvec, int lane, int wave) {
+    const int nchunks = nvec >> 6;
+    for (int c = wave; c < nchunks; c += 8) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + c * 64 + lane),
+                                         (__attribute__((address_space(3))) void*)(dst + c * 1024), 16, 0, 0);
+    }
+}
+
 // Implicit-GEMM over `ntiles` K-tiles of KT channels each (tiles_per_tap tiles per 3x3 tap).
 // acc[mi][ni] += A(positions x K) * B(K x columns). A rows come from `act` (row stride in_stride
-// bytes, zero row at zrow); B tiles are streamed from `wg` through the two LDS buffers at bbuf.
-template <int MI, int NI, int KT, int NST>
+// bytes, zero row at zrow); B tiles are streamed from `wg` through the two LDS buffers at bbuf,
+// tile t+1 in flight while tile t feeds the MFMAs.
+template <int MI, int NI, int KT>
 __device__ __forceinline__ void gemm_taps(f32x16 (&acc)[MI][NI], const uint4* __restrict__ wg, int ntiles, int tiles_per_tap,
                                           int N, bool three, const char* act, int in_stride, const char* zrow, char* bbuf,
                                           int n, const int (&ry)[MI], const int (&rx)[MI], const int (&rrow)[MI],
                                           const bool (&rvalid)[MI], int tid, int lane, int col0) {
     const int tile_bytes = KT * N * 2;
     const int nvec = tile_bytes / 16;
-    const int h = lane >> 5, l31 = lane & 31;
-    for (int i = tid; i < nvec; i += 512) ((uint4*)bbuf)[i] = wg[i];
+    const int h = lane >> 5, l31 = lane & 31, wave = tid >> 6;
+    stage_tile(wg, bbuf, nvec, lane, wave);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int t = 0; t < ntiles; ++t) {
         const char* cur = bbuf + (t & 1) * tile_bytes;
-        uint4 stage[NST];
-        if (t + 1 < ntiles) {
-#pragma unroll
-            for (int s = 0; s < NST; ++s) {
-                const int idx = tid + 512 * s;
-                if (idx < nvec) stage[s] = wg[(size_t)(t + 1) * nvec + idx];
-            }
-        }
+        if (t + 1 < ntiles) stage_tile(wg + (size_t)(t + 1) * nvec, bbuf + ((t + 1) & 1) * tile_bytes, nvec, lane, wave);
         const int tap = t / tiles_per_tap, c0 = (t - tap * tiles_per_tap) * KT;
         const int dy = three ? tap / 3 - 1 : 0, dx = three ? tap - (tap / 3) * 3 - 1 : 0;
         const char* ap[MI];
@@ -105,14 +124,7 @@ __device__ __forceinline__ void gemm_taps(f32x16 (&acc)[MI][NI], const uint4* __
                 for (int ni = 0; ni < NI; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
         }
-        if (t + 1 < ntiles) {
-            char* nxt = bbuf + ((t + 1) & 1) * tile_bytes;
-#pragma unroll
-            for (int s = 0; s < NST; ++s) {
-                const int idx = tid + 512 * s;
-                if (idx < nvec) ((uint4*)nxt)[idx] = stage[s];
-            }
-        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next tile has landed in LDS
         __syncthreads();
     }
 }
@@ -133,9 +145,6 @@ __global__ __launch_bounds__(512, 2) void k_tower(TowerParams P) {
     constexpr int MI = 256 / (WM * 32), NI = C / (WN * 32), NIH = NH / (WN * 32);
     constexpr int KT = C >= 64 ? 64 : 32;
     constexpr int STRIDE = 2 * C + 16;
-    constexpr int NST = (KT * C * 2 / 16 + 511) / 512;
-    constexpr int NST_STEM = (32 * C * 2 / 16 + 511) / 512;
-    constexpr int NST_H = (KT * NH * 2 / 16 + 511) / 512;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* act = smem;
     char* zrow = smem + 256 * STRIDE;
@@ -150,6 +159,10 @@ __global__ __launch_bounds__(512, 2) void k_tower(TowerParams P) {
     const int nb = min(P.TB, P.rows - board0);
     const int vrows = nb * NP;  // valid rows of this workgroup
 
+#ifdef AZ_STAMP
+    unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
+#endif
     // ---- stage 0: zero row, feature tile -> act (row stride 2*cin_pad+16)
     const int in_stride0 = 2 * P.cin_pad + 16;
     for (int i = tid; i < STRIDE / 4; i += 512) ((uint32_t*)zrow)[i] = 0;
@@ -207,20 +220,25 @@ __global__ __launch_bounds__(512, 2) void k_tower(TowerParams P) {
 
     // ---- stem (model.py:61-65)
     zero_acc<MI, NI>(acc);
-    gemm_taps<MI, NI, 32, NST_STEM>(acc, P.w_stem, 9 * (P.cin_pad / 32), P.cin_pad / 32, C, true, act, in_stride0, zrow, bbuf, n,
+    gemm_taps<MI, NI, 32>(acc, P.w_stem, 9 * (P.cin_pad / 32), P.cin_pad / 32, C, true, act, in_stride0, zrow, bbuf, n,
                                     ry, rx, rrow, rvalid, tid, lane, col0);
+    STAMP(0);
     store_act(P.b_stem, true);
+    STAMP(1);
 
     // ---- residual tower (model.py:25-40)
     const size_t conv_vecs = (size_t)9 * C * C * 2 / 16;
     for (int blk = 0; blk < P.blocks; ++blk) {
         zero_acc<MI, NI>(acc);
-        gemm_taps<MI, NI, KT, NST>(acc, P.w_tower + (size_t)(2 * blk) * conv_vecs, 9 * (C / KT), C / KT, C, true, act, STRIDE,
+        gemm_taps<MI, NI, KT>(acc, P.w_tower + (size_t)(2 * blk) * conv_vecs, 9 * (C / KT), C / KT, C, true, act, STRIDE,
                                    zrow, bbuf, n, ry, rx, rrow, rvalid, tid, lane, col0);
+        STAMP(2);
         store_act(P.b_tower + (size_t)(2 * blk) * C, false);
+        STAMP(3);
         zero_acc<MI, NI>(acc);
-        gemm_taps<MI, NI, KT, NST>(acc, P.w_tower + (size_t)(2 * blk + 1) * conv_vecs, 9 * (C / KT), C / KT, C, true, act, STRIDE,
+        gemm_taps<MI, NI, KT>(acc, P.w_tower + (size_t)(2 * blk + 1) * conv_vecs, 9 * (C / KT), C / KT, C, true, act, STRIDE,
                                    zrow, bbuf, n, ry, rx, rrow, rvalid, tid, lane, col0);
+        STAMP(2);
         const float* bias2 = P.b_tower + (size_t)(2 * blk + 1) * C;
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
@@ -230,53 +248,65 @@ __global__ __launch_bounds__(512, 2) void k_tower(TowerParams P) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mi][ni][r] += bv;
         }
-        if (P.use_se) {  // model.py:9-22, pooled per board in a fixed order
-            // Per-board channel sums are accumulated as 64-bit fixed point (2^-16 steps): integer
-            // addition is associative, so the pooled value of a board is bit-identical whichever
-            // slot of whichever workgroup it occupies.
-            long long* part = (long long*)scratch;             // [WM][TB][C]
-            float* pooled = (float*)(part + WM * P.TB * C);    // [TB][C]
+        if (P.use_se) {  // model.py:9-22
+            // Pooling reads the bf16 image of y back from LDS: one thread per (board, channel) adds the
+            // board's positions in index order, so the pooled value is bit-identical whichever slot of
+            // whichever workgroup the board occupies.
+            float* pooled = scratch;                           // [TB][C]
             float* hidden = pooled + P.TB * C;                 // [TB][hid]
             float* sc = hidden + P.TB * P.hid;                 // [TB][C]
-            for (int b = 0; b < P.TB; ++b) {
-                long long s[NI];
+            char* sew = (char*)(sc + P.TB * C);                // this block's SE weights, fetched while we pool
+            sew += (16 - ((size_t)(sew - smem) & 15)) & 15;
+            stage_tile(P.se_blob + (size_t)blk * P.se_vecs, sew, P.se_vecs, lane, wave);
+            const uint16_t* w1 = (const uint16_t*)sew;         // [hid][C] bf16
+            const uint16_t* w2t = w1 + P.hid * C;              // [hid][C] bf16 (fc2 weight transposed)
+            const float* b1 = (const float*)(w2t + P.hid * C);
+            const float* b2 = b1 + P.hid;
+            __syncthreads();  // every wave has finished reading conv2's input from act
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) s[ni] = 0;
-                const int lo = b * NP, hi = lo + NP;
-                if (b < nb && lo < row_base + 32 * MI && hi > row_base) {
+            for (int ni = 0; ni < NI; ++ni) {
+                const int col = col0 + ni * 32 + l31;
 #pragma unroll
-                    for (int mi = 0; mi < MI; ++mi)
+                for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int row = row_base + mi * 32 + 4 * h + (r & 3) + 8 * (r >> 2);
-                            const bool in = row >= lo && row < hi;
-#pragma unroll
-                            for (int ni = 0; ni < NI; ++ni) s[ni] += in ? (long long)__float2int_rn(acc[mi][ni][r] * 65536.f) : 0ll;
-                        }
-                }
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni) {
-                    s[ni] += __shfl_xor(s[ni], 32);
-                    if (h == 0) part[(wm * P.TB + b) * C + col0 + ni * 32 + l31] = s[ni];
-                }
+                    for (int r = 0; r < 16; r += 2) {
+                        const int row = row_base + mi * 32 + 4 * h + (r & 3) + 8 * (r >> 2);
+                        const uint32_t pk = pack_bf16(acc[mi][ni][r], acc[mi][ni][r + 1]);
+                        *(uint16_t*)(act + row * STRIDE + col * 2) = (uint16_t)(pk & 0xffffu);
+                        *(uint16_t*)(act + (row + 1) * STRIDE + col * 2) = (uint16_t)(pk >> 16);
+                    }
             }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             const float inv_np = 1.0f / (float)NP;
-            for (int i = tid; i < P.TB * C; i += 512) {
-                long long s = 0;
+            for (int i = tid; i < nb * (C / 2); i += 512) {   // two adjacent channels per thread
+                const int b = i / (C / 2), cp = i - b * (C / 2);
+                const char* src = act + (size_t)b * NP * STRIDE + cp * 4;
+                float s0 = 0.f, s1 = 0.f;
+                int p = 0;
+                for (; p + 9 <= NP; p += 9) {   // loads batched nine at a time, adds in position order
+                    uint32_t v[9];
 #pragma unroll
-                for (int w = 0; w < WM; ++w) s += part[w * P.TB * C + i];
-                pooled[i] = (float)s * (1.0f / 65536.f) * inv_np;
+                    for (int k = 0; k < 9; ++k) v[k] = *(const uint32_t*)(src + (p + k) * STRIDE);
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) { s0 += bf16_lo(v[k]); s1 += bf16_hi(v[k]); }
+                }
+                for (; p < NP; ++p) {
+                    const uint32_t v = *(const uint32_t*)(src + p * STRIDE);
+                    s0 += bf16_lo(v); s1 += bf16_hi(v);
+                }
+                pooled[b * C + 2 * cp] = s0 * inv_np;
+                pooled[b * C + 2 * cp + 1] = s1 * inv_np;
             }
             __syncthreads();
-            {   // fc1 + relu: 8 lanes per output
-                const float* w1 = P.se_w1 + (size_t)blk * P.hid * C;
-                const float* b1 = P.se_b1 + (size_t)blk * P.hid;
+            {   // fc1 + relu: 8 lanes per output, fixed reduction tree
                 const int sub = tid & 7;
-                for (int o = tid >> 3; o < P.TB * P.hid; o += 64) {
+                for (int o = tid >> 3; o < nb * P.hid; o += 64) {
                     const int b = o / P.hid, j = o - b * P.hid;
                     float s = 0.f;
-                    for (int ch = sub; ch < C; ch += 8) s = fmaf(w1[j * C + ch], pooled[b * C + ch], s);
+#pragma unroll
+                    for (int ch = 0; ch < C; ch += 8)
+                        s = fmaf(__uint_as_float((uint32_t)w1[j * C + ch + sub] << 16), pooled[b * C + ch + sub], s);
                     s += __shfl_xor(s, 1);
                     s += __shfl_xor(s, 2);
                     s += __shfl_xor(s, 4);
@@ -284,34 +314,63 @@ __global__ __launch_bounds__(512, 2) void k_tower(TowerParams P) {
                 }
             }
             __syncthreads();
-            {   // fc2 + sigmoid
-                const float* w2 = P.se_w2 + (size_t)blk * C * P.hid;
-                const float* b2 = P.se_b2 + (size_t)blk * C;
-                for (int i = tid; i < P.TB * C; i += 512) {
-                    const int b = i / C, ch = i - b * C;
-                    float s = b2[ch];
-                    for (int j = 0; j < P.hid; ++j) s = fmaf(w2[ch * P.hid + j], hidden[b * P.hid + j], s);
-                    sc[i] = 1.f / (1.f + __expf(-s));
+            for (int i = tid; i < nb * C; i += 512) {   // fc2 + sigmoid
+                const int b = i / C, ch = i - b * C;
+                float s = b2[ch];
+                int j = 0;
+                for (; j + 8 <= P.hid; j += 8) {
+                    float w[8], hv[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { w[k] = __uint_as_float((uint32_t)w2t[(j + k) * C + ch] << 16); hv[k] = hidden[b * P.hid + j + k]; }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) s = fmaf(w[k], hv[k], s);
                 }
+                for (; j < P.hid; ++j) s = fmaf(__uint_as_float((uint32_t)w2t[j * C + ch] << 16), hidden[b * P.hid + j], s);
+                sc[i] = 1.f / (1.f + __expf(-s));
             }
             __syncthreads();
-            for (int b = 0; b < nb; ++b) {
-                const int lo = b * NP, hi = lo + NP;
-                if (lo >= row_base + 32 * MI || hi <= row_base) continue;
-                float sv[NI];
+            // A 32-row MFMA tile covers at most two boards when a board has >= 32 points: rows below
+            // `split` belong to board bA, the others to bA + 1.
+            if (NP >= 32) {
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) sv[ni] = sc[b * C + col0 + ni * 32 + l31];
+                for (int mi = 0; mi < MI; ++mi) {
+                    const int bA = ((row_base + mi * 32) * P.recip_np) >> 16, split = (bA + 1) * NP;
+                    float svA[NI], svB[NI];
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi)
+                    for (int ni = 0; ni < NI; ++ni) {
+                        const int col = col0 + ni * 32 + l31;
+                        svA[ni] = bA < nb ? sc[bA * C + col] : 1.f;
+                        svB[ni] = bA + 1 < nb ? sc[(bA + 1) * C + col] : 1.f;
+                    }
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = row_base + mi * 32 + 4 * h + (r & 3) + 8 * (r >> 2);
-                        const bool in = row >= lo && row < hi;
+                        const bool lower = row < split;
 #pragma unroll
-                        for (int ni = 0; ni < NI; ++ni) acc[mi][ni][r] = in ? acc[mi][ni][r] * sv[ni] : acc[mi][ni][r];
+                        for (int ni = 0; ni < NI; ++ni) acc[mi][ni][r] *= lower ? svA[ni] : svB[ni];
                     }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+                for (int b = 0; b < nb; ++b) {
+                    const int lo = b * NP, hi = lo + NP;
+                    if (lo >= row_base + 32 * MI || hi <= row_base) continue;
+                    float sv[NI];
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) sv[ni] = sc[b * C + col0 + ni * 32 + l31];
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int row = row_base + mi * 32 + 4 * h + (r & 3) + 8 * (r >> 2);
+                            const bool in = row >= lo && row < hi;
+#pragma unroll
+                            for (int ni = 0; ni < NI; ++ni) acc[mi][ni][r] = in ? acc[mi][ni][r] * sv[ni] : acc[mi][ni][r];
+                        }
+                }
             }
         }
+        STAMP(4);
         // x = relu(y + x) (model.py:40); act <- bf16(x); residual stays in registers
         __syncthreads();
 #pragma unroll
@@ -331,14 +390,16 @@ __global__ __launch_bounds__(512, 2) void k_tower(TowerParams P) {
                 }
         }
         __syncthreads();
+        STAMP(5);
     }
 
     // ---- both 1x1 head convolutions as one GEMM (model.py:68-71, :78-81)
+    STAMP(5);
     {
         f32x16 hacc[MI][NIH];
         zero_acc<MI, NIH>(hacc);
         const int hcol0 = wn * (NIH * 32);
-        gemm_taps<MI, NIH, KT, NST_H>(hacc, P.w_head, C / KT, C / KT, NH, false, act, STRIDE, zrow, bbuf, n, ry, rx, rrow, rvalid,
+        gemm_taps<MI, NIH, KT>(hacc, P.w_head, C / KT, C / KT, NH, false, act, STRIDE, zrow, bbuf, n, ry, rx, rrow, rvalid,
                                       tid, lane, hcol0);
         const int q2 = 2 * P.q;
 #pragma unroll
@@ -355,6 +416,11 @@ __global__ __launch_bounds__(512, 2) void k_tower(TowerParams P) {
                 }
         }
     }
+    STAMP(6);
+#ifdef AZ_STAMP
+    if (tid == 0 && P.stamps)
+        for (int i = 0; i < 8; ++i) P.stamps[(size_t)blockIdx.x * 8 + i] = stamp_acc[i];
+#endif
 }
 
 // Policy tail (model.py:72-76, :93-94): 1x1 conv q->2 + BN + ReLU, flatten channel-major, linear.
@@ -467,13 +533,19 @@ bool mfma_supported(const az_net_config& c) {
     return cok && c.board_size <= 9 && c.board_size >= 2 && c.in_planes <= 64;
 }
 
+static size_t se_blob_bytes(int C, int hid) {  // per block: w1, w2^T (bf16), b1, b2 (f32), padded to 1 KiB
+    const size_t raw = (size_t)2 * hid * C * 2 + (size_t)(hid + C) * 4;
+    return (raw + 1023) / 1024 * 1024;
+}
+
 // LDS: activations, zero row, then a region shared by the two weight staging buffers and the
-// squeeze-excite scratch (int64 partials [WM][TB][C], pooled [TB][C], hidden [TB][hid], scale [TB][C]).
+// squeeze-excite scratch (pooled [TB][C], hidden [TB][hid], scale [TB][C],
+// the block's SE weights).
 static size_t tower_lds_bytes(int C, int NH, int TB, int hid) {
-    const int KT = C >= 64 ? 64 : 32, WM = C == 32 ? 8 : 4;
+    const int KT = C >= 64 ? 64 : 32;
     const size_t stride = 2 * C + 16;
     const size_t tile = (size_t)KT * std::max(C, NH) * 2;
-    const size_t se = ((size_t)(2 * WM + 2) * TB * C + (size_t)TB * hid) * 4;
+    const size_t se = ((size_t)2 * TB * C + (size_t)TB * hid) * 4 + 16 + se_blob_bytes(C, hid);
     return 256 * stride + ((stride + 127) / 128) * 128 + std::max(2 * tile, se);
 }
 
@@ -508,7 +580,9 @@ int mfma_create(const az_net_config& c, const NetLayout& L, const float* Pm, Mfm
     }
     {   // tower
         std::vector<uint16_t> all;
-        std::vector<float> ball, w1, b1, w2, b2;
+        std::vector<float> ball;
+        const size_t blob_bytes = se_blob_bytes(C, c.se_hidden);
+        std::vector<uint8_t> blob(c.use_se ? blob_bytes * c.blocks : 0, 0);
         for (int i = 0; i < c.blocks; ++i) {
             const BlockOff& bo = L.blocks[i];
             fold_bn(Pm, bo.conv1, bo.bn1, C, (int64_t)C * 9, w, b);
@@ -518,17 +592,25 @@ int mfma_create(const az_net_config& c, const NetLayout& L, const float* Pm, Mfm
             pk = pack_conv(w, C, C, 9, C, C, KT);
             all.insert(all.end(), pk.begin(), pk.end()); ball.insert(ball.end(), b.begin(), b.end());
             if (c.use_se) {
-                w1.insert(w1.end(), Pm + bo.se_w1, Pm + bo.se_w1 + (int64_t)c.se_hidden * C);
-                b1.insert(b1.end(), Pm + bo.se_b1, Pm + bo.se_b1 + c.se_hidden);
-                w2.insert(w2.end(), Pm + bo.se_w2, Pm + bo.se_w2 + (int64_t)C * c.se_hidden);
-                b2.insert(b2.end(), Pm + bo.se_b2, Pm + bo.se_b2 + C);
+                const int hid = c.se_hidden;
+                uint8_t* dst = blob.data() + blob_bytes * i;
+                uint16_t* w1 = (uint16_t*)dst;
+                uint16_t* w2t = w1 + (size_t)hid * C;
+                float* b1 = (float*)(w2t + (size_t)hid * C);
+                float* b2 = b1 + hid;
+                for (int j = 0; j < hid; ++j)
+                    for (int ch = 0; ch < C; ++ch) {
+                        w1[(size_t)j * C + ch] = f2bf(Pm[bo.se_w1 + (int64_t)j * C + ch]);
+                        w2t[(size_t)j * C + ch] = f2bf(Pm[bo.se_w2 + (int64_t)ch * hid + j]);
+                    }
+                memcpy(b1, Pm + bo.se_b1, sizeof(float) * hid);
+                memcpy(b2, Pm + bo.se_b2, sizeof(float) * C);
             }
         }
-        uint16_t* d; float* f;
+        uint16_t* d; float* f; uint8_t* bl;
         TRY(up(m, all, &d)); P.w_tower = (const uint4*)d;
         TRY(up(m, ball, &f)); P.b_tower = f;
-        TRY(up(m, w1, &f)); P.se_w1 = f; TRY(up(m, b1, &f)); P.se_b1 = f;
-        TRY(up(m, w2, &f)); P.se_w2 = f; TRY(up(m, b2, &f)); P.se_b2 = f;
+        TRY(up(m, blob, &bl)); P.se_blob = (const uint4*)bl; P.se_vecs = (int)(blob_bytes / 16);
     }
     {   // fused head 1x1: columns [0,q) policy_head.0, [q,2q) value_head.0
         std::vector<float> wp, bp, wv, bv, wh((size_t)2 * q * C), bh(m->NH, 0.f);
@@ -625,7 +707,18 @@ int mfma_forward(MfmaNet* m, const void* feat, int rows, float* logits, float* v
     P.rows = rows;
     P.feat = (const uint16_t*)feat;
     P.hq = m->hq;
+    P.stamps = nullptr;
     const int grid = (rows + m->TB - 1) / m->TB;
+#ifdef AZ_STAMP
+    static unsigned long long* stamp_dev = nullptr;
+    static int stamp_grid = 0;
+    if (grid > stamp_grid) {
+        if (stamp_dev) (void)hipFree(stamp_dev);
+        (void)hipMalloc((void**)&stamp_dev, (size_t)grid * 64);
+        stamp_grid = grid;
+    }
+    P.stamps = stamp_dev;
+#endif
     const size_t lds = tower_lds_bytes(C, m->NH, m->TB, c.se_hidden);
     std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
     if (m->profiling) {
@@ -652,6 +745,19 @@ int mfma_forward(MfmaNet* m, const void* feat, int rows, float* logits, float* v
                        c.value_hidden);
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return fail(AZ_ERR_HIP, std::string("bf16 forward: ") + hipGetErrorString(err));
+#ifdef AZ_STAMP
+    {   // diagnostic build: print where a workgroup's cycles go (mean over workgroups)
+        std::vector<unsigned long long> hst((size_t)grid * 8);
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpy(hst.data(), P.stamps, hst.size() * 8, hipMemcpyDeviceToHost);
+        double sum[8] = {0};
+        for (int g = 0; g < grid; ++g) for (int i = 0; i < 8; ++i) sum[i] += (double)hst[(size_t)g * 8 + i];
+        const char* nm[8] = {"load+stem gemm", "stem epilogue", "conv gemm (2/blk)", "conv1 epilogue", "SE (pool+fc+scale)", "residual epilogue", "head gemm+store", "-"};
+        double tot = 0; for (int i = 0; i < 7; ++i) tot += sum[i];
+        fprintf(stderr, "[AZ_STAMP] rows=%d grid=%d mean cycles/WG=%.0f\n", rows, grid, tot / grid);
+        for (int i = 0; i < 7; ++i) fprintf(stderr, "  %-20s %10.0f  %5.1f%%\n", nm[i], sum[i] / grid, 100.0 * sum[i] / tot);
+    }
+#endif
     return AZ_OK;
 }
 
