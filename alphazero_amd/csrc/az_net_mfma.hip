@@ -17,6 +17,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -35,6 +36,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 struct TowerParams {
     int n, np, TB, rows, blocks, use_se, hid, cin_pad, q;
     unsigned recip_np;           // floor(row / np) == (row * recip_np) >> 16 for row < 512
+    unsigned recip_n;            // floor(p / n) == (p * recip_n) >> 16 for p < 512
     const uint16_t* feat;        // [rows][np][cin_pad] bf16
     const uint4* w_stem;         // packed tiles
     const float* b_stem;         // [C]
@@ -45,6 +47,8 @@ struct TowerParams {
     const uint4* w_head;         // packed 1x1, NH columns (policy q | value q | zero pad)
     const float* b_head;         // [NH]
     uint16_t* hq;                // out: [rows][np][2q] bf16, relu(bn(conv1x1)) of both heads
+    uint4* xres;                 // residual stream scratch: [gridDim.x][MI*NI*2][threads] 16-byte vectors, private per thread
+    int items;                   // board groups (of TB boards) to process; workgroups stride over them
     unsigned long long* stamps;  // diagnostic build (-DAZ_STAMP) only: per-workgroup phase cycle sums
 };
 
@@ -66,6 +70,12 @@ __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
     bf16x2 v = {(__bf16)a, (__bf16)b};
     return __builtin_bit_cast(uint32_t, v);
 }
+// Makes a value opaque to the optimiser at this point, so address arithmetic derived from it is
+// recomputed where it is used instead of being hoisted out of the layer loop and spilled.
+__device__ __forceinline__ int opaque(int x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
 __device__ __forceinline__ float bf16_lo(uint32_t u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf16_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
 __device__ __forceinline__ uint16_t to_bf16(float a) {
@@ -75,55 +85,103 @@ __device__ __forceinline__ uint16_t to_bf16(float a) {
 
 // Asynchronous global -> LDS copy of one packed weight tile (nvec 16-byte vectors, a multiple of 64):
 // every wave-instruction moves 1 KiB (64 lanes x 16 B) straight into LDS, no staging registers.
+template <int NW>
 __device__ __forceinline__ void stage_tile(const uint4* __restrict__ src, char* dst, int nvec, int lane, int wave) {
     const int nchunks = nvec >> 6;
-    for (int c = wave; c < nchunks; c += 8) {
+    for (int c = wave; c < nchunks; c += NW) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + c * 64 + lane),
                                          (__attribute__((address_space(3))) void*)(dst + c * 1024), 16, 0, 0);
     }
 }
 
+// Per-lane coordinates inside the workgroup tile. Every phase of the kernel re-derives them from an
+// opaque copy of threadIdx.x, so nothing computed from them is hoisted across the big layer loop
+// (the optimiser otherwise precomputes hundreds of addresses there and spills them).
+#define AZ_LANE_GEO(NI_)                                                                          \
+    const int t_ = opaque((int)threadIdx.x);                                                      \
+    const int lane = t_ & 63, wave = t_ >> 6, wm = wave / WN, wn = wave - wm * WN;                \
+    const int h = lane >> 5, l31 = lane & 31;                                                     \
+    const int row_base = wm * (32 * MI), col0 = wn * ((NI_) * 32);                                \
+    (void)row_base; (void)col0; (void)h; (void)l31; (void)wave
+
+struct TileGeo {   // wave-uniform facts about the workgroup's tile
+    int n, np, vrows;
+    unsigned recip_np, recip_n;
+};
+
 // Implicit-GEMM over `ntiles` K-tiles of KT channels each (tiles_per_tap tiles per 3x3 tap).
 // acc[mi][ni] += A(positions x K) * B(K x columns). A rows come from `act` (row stride in_stride
 // bytes, zero row at zrow); B tiles are streamed from `wg` through the two LDS buffers at bbuf,
 // tile t+1 in flight while tile t feeds the MFMAs.
-template <int MI, int NI, int KT>
+template <int MI, int NI, int KT, int WM, int WN>
 __device__ __forceinline__ void gemm_taps(f32x16 (&acc)[MI][NI], const uint4* __restrict__ wg, int ntiles, int tiles_per_tap,
                                           int N, bool three, const char* act, int in_stride, const char* zrow, char* bbuf,
-                                          int n, const int (&ry)[MI], const int (&rx)[MI], const int (&rrow)[MI],
-                                          const bool (&rvalid)[MI], int tid, int lane, int col0) {
+                                          const TileGeo& g) {
+    constexpr int NW = WM * WN;
+    AZ_LANE_GEO(NI);
     const int tile_bytes = KT * N * 2;
     const int nvec = tile_bytes / 16;
-    const int h = lane >> 5, l31 = lane & 31, wave = tid >> 6;
-    stage_tile(wg, bbuf, nvec, lane, wave);
+    stage_tile<NW>(wg, bbuf, nvec, lane, wave);
+    // row geometry of this lane's A fragments
+    int ry[MI], rx[MI], roff[MI];
+    bool rvalid[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int row = row_base + mi * 32 + l31;
+        const int b = (row * g.recip_np) >> 16, p = row - b * g.np;
+        ry[mi] = (p * g.recip_n) >> 16;
+        rx[mi] = p - ry[mi] * g.n;
+        roff[mi] = row * in_stride;
+        rvalid[mi] = row < g.vrows;
+    }
+    const int zoff = (int)(zrow - act);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int t = 0; t < ntiles; ++t) {
         const char* cur = bbuf + (t & 1) * tile_bytes;
-        if (t + 1 < ntiles) stage_tile(wg + (size_t)(t + 1) * nvec, bbuf + ((t + 1) & 1) * tile_bytes, nvec, lane, wave);
+        if (t + 1 < ntiles) stage_tile<NW>(wg + (size_t)(t + 1) * nvec, bbuf + ((t + 1) & 1) * tile_bytes, nvec, lane, wave);
         const int tap = t / tiles_per_tap, c0 = (t - tap * tiles_per_tap) * KT;
         const int dy = three ? tap / 3 - 1 : 0, dx = three ? tap - (tap / 3) * 3 - 1 : 0;
         const char* ap[MI];
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
             const int yy = ry[mi] + dy, xx = rx[mi] + dx;
-            const bool ok = rvalid[mi] && yy >= 0 && yy < n && xx >= 0 && xx < n;
-            ap[mi] = (ok ? act + (rrow[mi] + dy * n + dx) * in_stride : zrow) + c0 * 2 + h * 16;
+            const bool ok = rvalid[mi] & ((unsigned)yy < (unsigned)g.n) & ((unsigned)xx < (unsigned)g.n);
+            const int off = ok ? roff[mi] + (dy * g.n + dx) * in_stride : zoff;
+            ap[mi] = act + off + c0 * 2 + h * 16;
         }
         const char* bp = cur + ((size_t)h * N + col0 + l31) * 16;
+        // fragments of k-step ks+1 are fetched from LDS while the MFMAs of k-step ks run
+        constexpr int KS = KT / 16;
+        bf16x8 a[2][MI], b[2][NI];
 #pragma unroll
-        for (int ks = 0; ks < KT / 16; ++ks) {
-            bf16x8 a[MI], b[NI];
+        for (int mi = 0; mi < MI; ++mi) a[0][mi] = *(const bf16x8*)(ap[mi]);
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) a[mi] = *(const bf16x8*)(ap[mi] + ks * 32);
+        for (int ni = 0; ni < NI; ++ni) b[0][ni] = *(const bf16x8*)(bp + (size_t)(ni * 32) * 16);
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) b[ni] = *(const bf16x8*)(bp + ((size_t)ks * 2 * N + ni * 32) * 16);
+        for (int ks = 0; ks < KS; ++ks) {
+            if (ks + 1 < KS) {
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) a[(ks + 1) & 1][mi] = *(const bf16x8*)(ap[mi] + (ks + 1) * 32);
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                    b[(ks + 1) & 1][ni] = *(const bf16x8*)(bp + ((size_t)(ks + 1) * 2 * N + ni * 32) * 16);
+            }
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks & 1][mi], b[ks & 1][ni], acc[mi][ni], 0, 0, 0);
         }
+        // pin the software pipeline: the LDS reads of k-step ks+1 are issued between the MFMAs of k-step ks
+        __builtin_amdgcn_sched_group_barrier(0x100, MI + NI, 0);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int i = 0; i < MI * NI; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (ks + 1 < KS && i < MI + NI) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next tile has landed in LDS
         __syncthreads();
     }
@@ -139,284 +197,307 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[MI][NI]) {
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 }
 
-// C channels; WM x WN waves (WM*WN == 8); NH = padded column count of the fused head 1x1 conv.
-template <int C, int WM, int WN, int NH>
-__global__ __launch_bounds__(512, 2) void k_tower(TowerParams P) {
-    constexpr int MI = 256 / (WM * 32), NI = C / (WN * 32), NIH = NH / (WN * 32);
-    constexpr int KT = C >= 64 ? 64 : 32;
-    constexpr int STRIDE = 2 * C + 16;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* act = smem;
-    char* zrow = smem + 256 * STRIDE;
-    char* bbuf = zrow + ((STRIDE + 127) / 128) * 128;
-    float* scratch = (float*)bbuf;  // epilogue scratch shares the weight staging buffers
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const int h = lane >> 5, l31 = lane & 31;
-    const int n = P.n, NP = P.np;
-    const int board0 = blockIdx.x * P.TB;
-    const int nb = min(P.TB, P.rows - board0);
-    const int vrows = nb * NP;  // valid rows of this workgroup
-
-#ifdef AZ_STAMP
-    unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
-#endif
-    // ---- stage 0: zero row, feature tile -> act (row stride 2*cin_pad+16)
-    const int in_stride0 = 2 * P.cin_pad + 16;
-    for (int i = tid; i < STRIDE / 4; i += 512) ((uint32_t*)zrow)[i] = 0;
-    {
-        const int ppr = P.cin_pad * 2 / 16;  // 16-byte pieces per row
-        const uint4* src = (const uint4*)(P.feat + (size_t)board0 * NP * P.cin_pad);
-        for (int i = tid; i < 256 * ppr; i += 512) {
-            const int row = i / ppr, part = i - row * ppr;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (row < vrows) v = src[i];
-            *(uint4*)(act + row * in_stride0 + part * 16) = v;
-        }
-    }
-    // per-lane A-row geometry
-    int ry[MI], rx[MI], rrow[MI];
-    bool rvalid[MI];
+// act <- bf16(f(acc + bias)) with f = relu or identity; optionally park the packed values in xres
+// (the residual stream: each thread's private slice, L2-resident traffic).
+template <int MI, int NI, int WM, int WN, int STRIDE, bool RELU, bool KEEP>
+__device__ __forceinline__ void store_act(const f32x16 (&acc)[MI][NI], const float* __restrict__ bias, char* act, uint4* xres_wg) {
+    constexpr int NT = 64 * WM * WN;
+    AZ_LANE_GEO(NI);
+    __syncthreads();  // every wave has finished reading act
+    char* wbase = act + (row_base + 4 * h) * STRIDE + (col0 + l31) * 2;
+    uint4* xr = xres_wg + t_;
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-        const int row = wm * (32 * MI) + mi * 32 + l31;
-        const int b = (row * P.recip_np) >> 16, p = row - b * NP;
-        rrow[mi] = row;
-        ry[mi] = p / n;
-        rx[mi] = p - ry[mi] * n;
-        rvalid[mi] = row < vrows;
-    }
-    const int col0 = wn * (NI * 32);
-    const int row_base = wm * (32 * MI);
-    __syncthreads();
-
-    f32x16 acc[MI][NI];
-    uint32_t res[MI][NI][8];
-
-    // write relu(acc + bias) as bf16 into act; optionally keep it as the residual
-    auto store_act = [&](const float* bias, bool keep_res) {
-        __syncthreads();  // every wave has finished reading act
+    for (int ni = 0; ni < NI; ++ni) {
+        const float bv = bias ? bias[col0 + ni * 32 + l31] : 0.f;
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-            const int col = col0 + ni * 32 + l31;
-            const float bv = bias[col];
+        for (int mi = 0; mi < MI; ++mi) {
+            uint32_t pk[8];
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {
-#pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    const int row = row_base + mi * 32 + 4 * h + (r & 3) + 8 * (r >> 2);
-                    const float v0 = fmaxf(acc[mi][ni][r] + bv, 0.f), v1 = fmaxf(acc[mi][ni][r + 1] + bv, 0.f);
-                    const uint32_t pk = pack_bf16(v0, v1);
-                    if (keep_res) res[mi][ni][r >> 1] = pk;
-                    *(uint16_t*)(act + row * STRIDE + col * 2) = (uint16_t)(pk & 0xffffu);
-                    *(uint16_t*)(act + (row + 1) * STRIDE + col * 2) = (uint16_t)(pk >> 16);
-                }
+            for (int r = 0; r < 16; r += 2) {
+                const int off = (mi * 32 + (r & 3) + 8 * (r >> 2)) * STRIDE + ni * 64;
+                float v0 = acc[mi][ni][r] + bv, v1 = acc[mi][ni][r + 1] + bv;
+                if (RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+                pk[r >> 1] = pack_bf16(v0, v1);
+                *(uint16_t*)(wbase + off) = (uint16_t)(pk[r >> 1] & 0xffffu);
+                *(uint16_t*)(wbase + off + STRIDE) = (uint16_t)(pk[r >> 1] >> 16);
+            }
+            if (KEEP) {
+                xr[(size_t)((mi * NI + ni) * 2) * NT] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                xr[(size_t)((mi * NI + ni) * 2 + 1) * NT] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
             }
         }
-        __syncthreads();
-    };
+    }
+    __syncthreads();
+}
 
-    // ---- stem (model.py:61-65)
-    zero_acc<MI, NI>(acc);
-    gemm_taps<MI, NI, 32>(acc, P.w_stem, 9 * (P.cin_pad / 32), P.cin_pad / 32, C, true, act, in_stride0, zrow, bbuf, n,
-                                    ry, rx, rrow, rvalid, tid, lane, col0);
-    STAMP(0);
-    store_act(P.b_stem, true);
-    STAMP(1);
-
-    // ---- residual tower (model.py:25-40)
-    const size_t conv_vecs = (size_t)9 * C * C * 2 / 16;
-    for (int blk = 0; blk < P.blocks; ++blk) {
-        zero_acc<MI, NI>(acc);
-        gemm_taps<MI, NI, KT>(acc, P.w_tower + (size_t)(2 * blk) * conv_vecs, 9 * (C / KT), C / KT, C, true, act, STRIDE,
-                                   zrow, bbuf, n, ry, rx, rrow, rvalid, tid, lane, col0);
-        STAMP(2);
-        store_act(P.b_tower + (size_t)(2 * blk) * C, false);
-        STAMP(3);
-        zero_acc<MI, NI>(acc);
-        gemm_taps<MI, NI, KT>(acc, P.w_tower + (size_t)(2 * blk + 1) * conv_vecs, 9 * (C / KT), C / KT, C, true, act, STRIDE,
-                                   zrow, bbuf, n, ry, rx, rrow, rvalid, tid, lane, col0);
-        STAMP(2);
-        const float* bias2 = P.b_tower + (size_t)(2 * blk + 1) * C;
+// Squeeze-excite gate of one block (model.py:9-22) applied to acc in place. The bf16 image of y is
+// in act; pooled/hidden/scale and the block's SE weights live in `scratch` (the idle weight buffers).
+template <int MI, int NI, int WM, int WN, int C, int STRIDE>
+__device__ __forceinline__ void se_gate(f32x16 (&acc)[MI][NI], const char* act, float* scratch, const uint4* __restrict__ blob, int se_vecs,
+                                        int hid, int TB, int nb, const TileGeo& g) {
+    constexpr int NW = WM * WN, NT = 64 * NW;
+    AZ_LANE_GEO(NI);
+    const int NP = g.np;
+    float* pooled = scratch;                 // [TB][C]
+    float* hidden = pooled + TB * C;         // [TB][hid]
+    float* sc = hidden + TB * hid;           // [TB][C]
+    char* sew = (char*)(sc + TB * C);        // this block's SE weights
+    sew += (16 - ((size_t)(sew - (char*)scratch) & 15)) & 15;
+    stage_tile<NW>(blob, sew, se_vecs, lane, wave);
+    const uint16_t* w1 = (const uint16_t*)sew;   // [hid][C] bf16
+    const uint16_t* w2t = w1 + hid * C;          // [hid][C] bf16 (fc2 weight transposed)
+    const float* b1 = (const float*)(w2t + hid * C);
+    const float* b2 = b1 + hid;
+    // Pooling: one thread per (board, channel pair) adds the board's positions in index order, so the
+    // pooled value is bit-identical whichever slot of whichever workgroup the board occupies.
+    const float inv_np = 1.0f / (float)NP;
+    for (int i = t_; i < nb * (C / 2); i += NT) {
+        const int b = i / (C / 2), cp = i - b * (C / 2);
+        const char* src = act + (size_t)b * NP * STRIDE + cp * 4;
+        float s0 = 0.f, s1 = 0.f;
+        int p = 0;
+        for (; p + 9 <= NP; p += 9) {   // loads batched nine at a time, adds in position order
+            uint32_t v[9];
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-            const float bv = bias2[col0 + ni * 32 + l31];
+            for (int k = 0; k < 9; ++k) v[k] = *(const uint32_t*)(src + (p + k) * STRIDE);
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mi][ni][r] += bv;
+            for (int k = 0; k < 9; ++k) { s0 += bf16_lo(v[k]); s1 += bf16_hi(v[k]); }
         }
-        if (P.use_se) {  // model.py:9-22
-            // Pooling reads the bf16 image of y back from LDS: one thread per (board, channel) adds the
-            // board's positions in index order, so the pooled value is bit-identical whichever slot of
-            // whichever workgroup the board occupies.
-            float* pooled = scratch;                           // [TB][C]
-            float* hidden = pooled + P.TB * C;                 // [TB][hid]
-            float* sc = hidden + P.TB * P.hid;                 // [TB][C]
-            char* sew = (char*)(sc + P.TB * C);                // this block's SE weights, fetched while we pool
-            sew += (16 - ((size_t)(sew - smem) & 15)) & 15;
-            stage_tile(P.se_blob + (size_t)blk * P.se_vecs, sew, P.se_vecs, lane, wave);
-            const uint16_t* w1 = (const uint16_t*)sew;         // [hid][C] bf16
-            const uint16_t* w2t = w1 + P.hid * C;              // [hid][C] bf16 (fc2 weight transposed)
-            const float* b1 = (const float*)(w2t + P.hid * C);
-            const float* b2 = b1 + P.hid;
-            __syncthreads();  // every wave has finished reading conv2's input from act
+        for (; p < NP; ++p) {
+            const uint32_t v = *(const uint32_t*)(src + p * STRIDE);
+            s0 += bf16_lo(v); s1 += bf16_hi(v);
+        }
+        pooled[b * C + 2 * cp] = s0 * inv_np;
+        pooled[b * C + 2 * cp + 1] = s1 * inv_np;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // SE weights have landed
+    __syncthreads();
+    {   // fc1 + relu: 8 lanes per output, fixed reduction tree
+        const int sub = t_ & 7;
+        for (int o = t_ >> 3; o < nb * hid; o += NT / 8) {
+            const int b = o / hid, j = o - b * hid;
+            float s = 0.f;
+#pragma unroll
+            for (int ch = 0; ch < C; ch += 8) s = fmaf(__uint_as_float((uint32_t)w1[j * C + ch + sub] << 16), pooled[b * C + ch + sub], s);
+            s += __shfl_xor(s, 1);
+            s += __shfl_xor(s, 2);
+            s += __shfl_xor(s, 4);
+            if (sub == 0) hidden[o] = fmaxf(s + b1[j], 0.f);
+        }
+    }
+    __syncthreads();
+    for (int i = t_; i < nb * C; i += NT) {   // fc2 + sigmoid
+        const int b = i / C, ch = i - b * C;
+        float s = b2[ch];
+        int j = 0;
+        for (; j + 8 <= hid; j += 8) {
+            float w[8], hv[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { w[k] = __uint_as_float((uint32_t)w2t[(j + k) * C + ch] << 16); hv[k] = hidden[b * hid + j + k]; }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s = fmaf(w[k], hv[k], s);
+        }
+        for (; j < hid; ++j) s = fmaf(__uint_as_float((uint32_t)w2t[j * C + ch] << 16), hidden[b * hid + j], s);
+        sc[i] = 1.f / (1.f + __expf(-s));
+    }
+    __syncthreads();
+    // A 32-row MFMA tile covers at most two boards when a board has >= 32 points: rows below
+    // `split` belong to board bA, the others to bA + 1.
+    if (NP >= 32) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int bA = ((row_base + mi * 32) * g.recip_np) >> 16, split = (bA + 1) * NP;
+            float svA[NI], svB[NI];
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
                 const int col = col0 + ni * 32 + l31;
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                    for (int r = 0; r < 16; r += 2) {
-                        const int row = row_base + mi * 32 + 4 * h + (r & 3) + 8 * (r >> 2);
-                        const uint32_t pk = pack_bf16(acc[mi][ni][r], acc[mi][ni][r + 1]);
-                        *(uint16_t*)(act + row * STRIDE + col * 2) = (uint16_t)(pk & 0xffffu);
-                        *(uint16_t*)(act + (row + 1) * STRIDE + col * 2) = (uint16_t)(pk >> 16);
-                    }
+                svA[ni] = bA < nb ? sc[bA * C + col] : 1.f;
+                svB[ni] = bA + 1 < nb ? sc[(bA + 1) * C + col] : 1.f;
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            const float inv_np = 1.0f / (float)NP;
-            for (int i = tid; i < nb * (C / 2); i += 512) {   // two adjacent channels per thread
-                const int b = i / (C / 2), cp = i - b * (C / 2);
-                const char* src = act + (size_t)b * NP * STRIDE + cp * 4;
-                float s0 = 0.f, s1 = 0.f;
-                int p = 0;
-                for (; p + 9 <= NP; p += 9) {   // loads batched nine at a time, adds in position order
-                    uint32_t v[9];
 #pragma unroll
-                    for (int k = 0; k < 9; ++k) v[k] = *(const uint32_t*)(src + (p + k) * STRIDE);
+            for (int r = 0; r < 16; ++r) {
+                const int row = row_base + 4 * h + mi * 32 + (r & 3) + 8 * (r >> 2);
+                const bool lower = row < split;
 #pragma unroll
-                    for (int k = 0; k < 9; ++k) { s0 += bf16_lo(v[k]); s1 += bf16_hi(v[k]); }
-                }
-                for (; p < NP; ++p) {
-                    const uint32_t v = *(const uint32_t*)(src + p * STRIDE);
-                    s0 += bf16_lo(v); s1 += bf16_hi(v);
-                }
-                pooled[b * C + 2 * cp] = s0 * inv_np;
-                pooled[b * C + 2 * cp + 1] = s1 * inv_np;
-            }
-            __syncthreads();
-            {   // fc1 + relu: 8 lanes per output, fixed reduction tree
-                const int sub = tid & 7;
-                for (int o = tid >> 3; o < nb * P.hid; o += 64) {
-                    const int b = o / P.hid, j = o - b * P.hid;
-                    float s = 0.f;
-#pragma unroll
-                    for (int ch = 0; ch < C; ch += 8)
-                        s = fmaf(__uint_as_float((uint32_t)w1[j * C + ch + sub] << 16), pooled[b * C + ch + sub], s);
-                    s += __shfl_xor(s, 1);
-                    s += __shfl_xor(s, 2);
-                    s += __shfl_xor(s, 4);
-                    if (sub == 0) hidden[o] = fmaxf(s + b1[j], 0.f);
-                }
-            }
-            __syncthreads();
-            for (int i = tid; i < nb * C; i += 512) {   // fc2 + sigmoid
-                const int b = i / C, ch = i - b * C;
-                float s = b2[ch];
-                int j = 0;
-                for (; j + 8 <= P.hid; j += 8) {
-                    float w[8], hv[8];
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) { w[k] = __uint_as_float((uint32_t)w2t[(j + k) * C + ch] << 16); hv[k] = hidden[b * P.hid + j + k]; }
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) s = fmaf(w[k], hv[k], s);
-                }
-                for (; j < P.hid; ++j) s = fmaf(__uint_as_float((uint32_t)w2t[j * C + ch] << 16), hidden[b * P.hid + j], s);
-                sc[i] = 1.f / (1.f + __expf(-s));
-            }
-            __syncthreads();
-            // A 32-row MFMA tile covers at most two boards when a board has >= 32 points: rows below
-            // `split` belong to board bA, the others to bA + 1.
-            if (NP >= 32) {
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi) {
-                    const int bA = ((row_base + mi * 32) * P.recip_np) >> 16, split = (bA + 1) * NP;
-                    float svA[NI], svB[NI];
-#pragma unroll
-                    for (int ni = 0; ni < NI; ++ni) {
-                        const int col = col0 + ni * 32 + l31;
-                        svA[ni] = bA < nb ? sc[bA * C + col] : 1.f;
-                        svB[ni] = bA + 1 < nb ? sc[(bA + 1) * C + col] : 1.f;
-                    }
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = row_base + mi * 32 + 4 * h + (r & 3) + 8 * (r >> 2);
-                        const bool lower = row < split;
-#pragma unroll
-                        for (int ni = 0; ni < NI; ++ni) acc[mi][ni][r] *= lower ? svA[ni] : svB[ni];
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            } else {
-                for (int b = 0; b < nb; ++b) {
-                    const int lo = b * NP, hi = lo + NP;
-                    if (lo >= row_base + 32 * MI || hi <= row_base) continue;
-                    float sv[NI];
-#pragma unroll
-                    for (int ni = 0; ni < NI; ++ni) sv[ni] = sc[b * C + col0 + ni * 32 + l31];
-#pragma unroll
-                    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int row = row_base + mi * 32 + 4 * h + (r & 3) + 8 * (r >> 2);
-                            const bool in = row >= lo && row < hi;
-#pragma unroll
-                            for (int ni = 0; ni < NI; ++ni) acc[mi][ni][r] = in ? acc[mi][ni][r] * sv[ni] : acc[mi][ni][r];
-                        }
-                }
+                for (int ni = 0; ni < NI; ++ni) acc[mi][ni][r] *= lower ? svA[ni] : svB[ni];
             }
         }
-        STAMP(4);
-        // x = relu(y + x) (model.py:40); act <- bf16(x); residual stays in registers
-        __syncthreads();
+    } else {
+        for (int b = 0; b < nb; ++b) {
+            const int lo = b * NP, hi = lo + NP;
+            if (lo >= row_base + 32 * MI || hi <= row_base) continue;
+            float sv[NI];
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-            const int col = col0 + ni * 32 + l31;
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    const int row = row_base + mi * 32 + 4 * h + (r & 3) + 8 * (r >> 2);
-                    const uint32_t old = res[mi][ni][r >> 1];
-                    const float v0 = fmaxf(acc[mi][ni][r] + bf16_lo(old), 0.f), v1 = fmaxf(acc[mi][ni][r + 1] + bf16_hi(old), 0.f);
-                    const uint32_t pk = pack_bf16(v0, v1);
-                    res[mi][ni][r >> 1] = pk;
-                    *(uint16_t*)(act + row * STRIDE + col * 2) = (uint16_t)(pk & 0xffffu);
-                    *(uint16_t*)(act + (row + 1) * STRIDE + col * 2) = (uint16_t)(pk >> 16);
-                }
-        }
-        __syncthreads();
-        STAMP(5);
-    }
-
-    // ---- both 1x1 head convolutions as one GEMM (model.py:68-71, :78-81)
-    STAMP(5);
-    {
-        f32x16 hacc[MI][NIH];
-        zero_acc<MI, NIH>(hacc);
-        const int hcol0 = wn * (NIH * 32);
-        gemm_taps<MI, NIH, KT>(hacc, P.w_head, C / KT, C / KT, NH, false, act, STRIDE, zrow, bbuf, n, ry, rx, rrow, rvalid,
-                                      tid, lane, hcol0);
-        const int q2 = 2 * P.q;
-#pragma unroll
-        for (int ni = 0; ni < NIH; ++ni) {
-            const int col = hcol0 + ni * 32 + l31;
-            if (col >= q2) continue;
-            const float bv = P.b_head[col];
+            for (int ni = 0; ni < NI; ++ni) sv[ni] = sc[b * C + col0 + ni * 32 + l31];
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = row_base + mi * 32 + 4 * h + (r & 3) + 8 * (r >> 2);
-                    if (row < vrows) P.hq[((size_t)board0 * NP + row) * q2 + col] = to_bf16(fmaxf(hacc[mi][ni][r] + bv, 0.f));
+                    const bool in = row >= lo && row < hi;
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) acc[mi][ni][r] = in ? acc[mi][ni][r] * sv[ni] : acc[mi][ni][r];
                 }
         }
     }
-    STAMP(6);
+}
+
+// x = relu(y + x) (model.py:40): act <- bf16(x); the new residual goes back to xres when `keep`.
+template <int MI, int NI, int WM, int WN, int STRIDE>
+__device__ __forceinline__ void residual_store(const f32x16 (&acc)[MI][NI], const uint4 (&resv)[MI * NI * 2], char* act, uint4* xres_wg,
+                                               bool keep) {
+    constexpr int NT = 64 * WM * WN;
+    AZ_LANE_GEO(NI);
+    __syncthreads();
+    char* wbase = act + (row_base + 4 * h) * STRIDE + (col0 + l31) * 2;
+    uint4* xr = xres_wg + t_;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const uint4 o0 = resv[(mi * NI + ni) * 2], o1 = resv[(mi * NI + ni) * 2 + 1];
+            const uint32_t old[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
+            uint32_t pk[8];
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const int off = (mi * 32 + (r & 3) + 8 * (r >> 2)) * STRIDE + ni * 64;
+                const float v0 = fmaxf(acc[mi][ni][r] + bf16_lo(old[r >> 1]), 0.f), v1 = fmaxf(acc[mi][ni][r + 1] + bf16_hi(old[r >> 1]), 0.f);
+                pk[r >> 1] = pack_bf16(v0, v1);
+                *(uint16_t*)(wbase + off) = (uint16_t)(pk[r >> 1] & 0xffffu);
+                *(uint16_t*)(wbase + off + STRIDE) = (uint16_t)(pk[r >> 1] >> 16);
+            }
+            if (keep) {
+                xr[(size_t)((mi * NI + ni) * 2) * NT] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                xr[(size_t)((mi * NI + ni) * 2 + 1) * NT] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// C channels; WM x WN waves (8 waves = two per SIMD with 256 registers each, or 4 waves = one per SIMD
+// with 512 registers each); NH = padded column count of the fused head 1x1 conv. One workgroup per CU
+// (LDS-bound), striding over the board groups.
+template <int C, int WM, int WN, int NH>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_tower(TowerParams P) {
+    constexpr int NW = WM * WN, NT = 64 * NW;
+    constexpr int MI = 256 / (WM * 32), NI = C / (WN * 32), NIH = NH / (WN * 32);
+    constexpr int KT = C >= 64 ? 64 : 32;
+    constexpr int STRIDE = 2 * C + 16;
+    constexpr int NV = MI * NI * 2;  // 16-byte vectors of packed bf16 residual per thread
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* act = smem;
+    char* zrow = smem + 256 * STRIDE;
+    char* bbuf = zrow + ((STRIDE + 127) / 128) * 128;
+    float* scratch = (float*)bbuf;  // epilogue scratch shares the weight staging buffers
+    const int tid = threadIdx.x;
+    uint4* xres_wg = P.xres + (size_t)blockIdx.x * NV * NT;
+#ifdef AZ_STAMP
+    unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
+#endif
+    for (int i = tid; i < STRIDE / 4; i += NT) ((uint32_t*)zrow)[i] = 0;
+    TileGeo g;
+    g.n = P.n; g.np = P.np; g.recip_np = P.recip_np; g.recip_n = P.recip_n;
+    for (int item = blockIdx.x; item < P.items; item += gridDim.x) {
+        const int board0 = item * P.TB;
+        const int nb = min(P.TB, P.rows - board0);
+        g.vrows = nb * P.np;  // valid rows of this workgroup
+        __syncthreads();      // the previous item's last LDS reads are done
+
+        // ---- stage 0: feature tile -> act (row stride 2*cin_pad+16)
+        const int in_stride0 = 2 * P.cin_pad + 16;
+        {
+            const int ppr = P.cin_pad * 2 / 16;  // 16-byte pieces per row
+            const uint4* src = (const uint4*)(P.feat + (size_t)board0 * P.np * P.cin_pad);
+            for (int i = tid; i < 256 * ppr; i += NT) {
+                const int row = i / ppr, part = i - row * ppr;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (row < g.vrows) v = src[i];
+                *(uint4*)(act + row * in_stride0 + part * 16) = v;
+            }
+        }
+        __syncthreads();
+
+        f32x16 acc[MI][NI];
+        // ---- stem (model.py:61-65)
+        zero_acc<MI, NI>(acc);
+        gemm_taps<MI, NI, 32, WM, WN>(acc, P.w_stem, 9 * (P.cin_pad / 32), P.cin_pad / 32, C, true, act, in_stride0, zrow, bbuf, g);
+        STAMP(0);
+        store_act<MI, NI, WM, WN, STRIDE, true, true>(acc, P.b_stem, act, xres_wg);
+        STAMP(1);
+
+        // ---- residual tower (model.py:25-40)
+        const size_t conv_vecs = (size_t)9 * C * C * 2 / 16;
+        for (int blk = 0; blk < P.blocks; ++blk) {
+            zero_acc<MI, NI>(acc);
+            gemm_taps<MI, NI, KT, WM, WN>(acc, P.w_tower + (size_t)(2 * blk) * conv_vecs, 9 * (C / KT), C / KT, C, true, act, STRIDE, zrow,
+                                          bbuf, g);
+            STAMP(2);
+            store_act<MI, NI, WM, WN, STRIDE, true, false>(acc, P.b_tower + (size_t)(2 * blk) * C, act, xres_wg);
+            STAMP(3);
+            zero_acc<MI, NI>(acc);
+            gemm_taps<MI, NI, KT, WM, WN>(acc, P.w_tower + (size_t)(2 * blk + 1) * conv_vecs, 9 * (C / KT), C / KT, C, true, act, STRIDE,
+                                          zrow, bbuf, g);
+            STAMP(2);
+            uint4 resv[NV];   // the block input, fetched now, consumed after the SE gate
+            {
+                const uint4* xr = xres_wg + opaque(tid);
+#pragma unroll
+                for (int v = 0; v < NV; ++v) resv[v] = xr[(size_t)v * NT];
+            }
+            {   // y = acc + bias (kept in registers in float32)
+                AZ_LANE_GEO(NI);
+                const float* bias2 = P.b_tower + (size_t)(2 * blk + 1) * C;
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const float bv = bias2[col0 + ni * 32 + l31];
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[mi][ni][r] += bv;
+                }
+            }
+            if (P.use_se) {
+                store_act<MI, NI, WM, WN, STRIDE, false, false>(acc, nullptr, act, xres_wg);   // bf16 image of y for the pooling
+                se_gate<MI, NI, WM, WN, C, STRIDE>(acc, act, scratch, P.se_blob + (size_t)blk * P.se_vecs, P.se_vecs, P.hid, P.TB, nb, g);
+            }
+            STAMP(4);
+            residual_store<MI, NI, WM, WN, STRIDE>(acc, resv, act, xres_wg, blk + 1 < P.blocks);
+            STAMP(5);
+        }
+
+        // ---- both 1x1 head convolutions as one GEMM (model.py:68-71, :78-81)
+        {
+            f32x16 hacc[MI][NIH];
+            zero_acc<MI, NIH>(hacc);
+            gemm_taps<MI, NIH, KT, WM, WN>(hacc, P.w_head, C / KT, C / KT, NH, false, act, STRIDE, zrow, bbuf, g);
+            // relu(acc + bias) -> LDS as [row][2q] bf16, then one coalesced copy: the workgroup's slice of hq is contiguous
+            AZ_LANE_GEO(NIH);
+            const int q2 = 2 * P.q, hstride = q2 * 2 + 16;
+            __syncthreads();  // every wave has finished reading act
+            char* hbase = act + (row_base + 4 * h) * hstride + (col0 + l31) * 2;
+#pragma unroll
+            for (int ni = 0; ni < NIH; ++ni) {
+                const int col = col0 + ni * 32 + l31;
+                if (col >= q2) continue;
+                const float bv = P.b_head[col];
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        *(uint16_t*)(hbase + (mi * 32 + (r & 3) + 8 * (r >> 2)) * hstride + ni * 64) = to_bf16(fmaxf(hacc[mi][ni][r] + bv, 0.f));
+            }
+            __syncthreads();
+            const int ppr = q2 * 2 / 16;  // 16-byte pieces per row (q2 is a multiple of 8)
+            uint4* dst = (uint4*)(P.hq + (size_t)board0 * P.np * q2);
+            for (int i = t_; i < g.vrows * ppr; i += NT) {
+                const int row = i / ppr, part = i - row * ppr;
+                dst[i] = *(const uint4*)(act + row * hstride + part * 16);
+            }
+        }
+        STAMP(6);
+    }  // item loop
 #ifdef AZ_STAMP
     if (tid == 0 && P.stamps)
         for (int i = 0; i < 8; ++i) P.stamps[(size_t)blockIdx.x * 8 + i] = stamp_acc[i];
@@ -490,6 +571,9 @@ struct MfmaNet {
     uint16_t* w4T;
     uint16_t* hq = nullptr;
     int hq_rows = 0;
+    uint4* xres = nullptr;   // residual-stream scratch for max_grid workgroups
+    int max_grid = 0;
+    int waves = 8;           // waves per workgroup of the C=192 tower (AZ_TOWER_WAVES=4 selects the 512-register variant)
     // optional timing of the tower kernel with HIP events on the launch stream
     bool profiling = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -567,8 +651,12 @@ int mfma_create(const az_net_config& c, const NetLayout& L, const float* Pm, Mfm
     P.n = c.board_size; P.np = np; P.TB = m->TB; P.blocks = c.blocks; P.use_se = c.use_se; P.hid = c.se_hidden;
     P.cin_pad = m->cin_pad; P.q = q;
     P.recip_np = (65536 + np - 1) / np;
+    P.recip_n = (65536 + c.board_size - 1) / c.board_size;
     for (int row = 0; row < 512; ++row)
-        if (((unsigned)row * P.recip_np) >> 16 != (unsigned)(row / np)) { delete m; return fail(AZ_ERR_ARG, "reciprocal division check failed"); }
+        if ((((unsigned)row * P.recip_np) >> 16 != (unsigned)(row / np)) || (((unsigned)row * P.recip_n) >> 16 != (unsigned)(row / c.board_size))) {
+            delete m;
+            return fail(AZ_ERR_ARG, "reciprocal division check failed");
+        }
     int rc;
 #define TRY(x) if ((rc = (x)) != AZ_OK) { mfma_destroy(m); return rc; }
     {   // stem
@@ -650,12 +738,22 @@ int mfma_create(const az_net_config& c, const NetLayout& L, const float* Pm, Mfm
         case 32: e = hipFuncSetAttribute((const void*)k_tower<32, 8, 1, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); break;
         case 64: e = hipFuncSetAttribute((const void*)k_tower<64, 4, 2, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); break;
         case 128: e = hipFuncSetAttribute((const void*)k_tower<128, 4, 2, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); break;
-        case 192: e = hipFuncSetAttribute((const void*)k_tower<192, 4, 2, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); break;
+        case 192:
+            e = hipFuncSetAttribute((const void*)k_tower<192, 2, 2, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_tower<192, 4, 2, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            break;
     }
     if (e != hipSuccess) { mfma_destroy(m); return fail(AZ_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); }
     const size_t vt = ((size_t)4 * q * np + 4 * c.value_hidden) * 4;
     e = hipFuncSetAttribute((const void*)k_value_tail<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vt);
     if (e != hipSuccess) { mfma_destroy(m); return fail(AZ_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); }
+    if (const char* w = getenv("AZ_TOWER_WAVES")) m->waves = atoi(w) == 4 ? 4 : 8;
+    {   // one workgroup per CU (LDS-bound), each striding over the board groups
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, c.device) != hipSuccess) { mfma_destroy(m); return fail(AZ_ERR_HIP, "hipGetDeviceProperties"); }
+        m->max_grid = std::max(1, prop.multiProcessorCount);
+        if (hipMalloc((void**)&m->xres, (size_t)m->max_grid * 256 * (size_t)C * 2) != hipSuccess) { mfma_destroy(m); return fail(AZ_ERR_HIP, "hipMalloc (residual scratch)"); }
+    }
     *out = m;
     return AZ_OK;
 }
@@ -689,6 +787,7 @@ void mfma_destroy(MfmaNet* m) {
     for (auto& e : m->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     for (void* p : m->allocs) (void)hipFree(p);
     if (m->hq) (void)hipFree(m->hq);
+    if (m->xres) (void)hipFree(m->xres);
     delete m;
 }
 
@@ -708,7 +807,9 @@ int mfma_forward(MfmaNet* m, const void* feat, int rows, float* logits, float* v
     P.feat = (const uint16_t*)feat;
     P.hq = m->hq;
     P.stamps = nullptr;
-    const int grid = (rows + m->TB - 1) / m->TB;
+    P.xres = m->xres;
+    P.items = (rows + m->TB - 1) / m->TB;
+    const int grid = std::min(P.items, m->max_grid);
 #ifdef AZ_STAMP
     static unsigned long long* stamp_dev = nullptr;
     static int stamp_grid = 0;
@@ -735,7 +836,10 @@ int mfma_forward(MfmaNet* m, const void* feat, int rows, float* logits, float* v
         case 32: hipLaunchKernelGGL((k_tower<32, 8, 1, 32>), dim3(grid), dim3(512), lds, st, P); break;
         case 64: hipLaunchKernelGGL((k_tower<64, 4, 2, 64>), dim3(grid), dim3(512), lds, st, P); break;
         case 128: hipLaunchKernelGGL((k_tower<128, 4, 2, 64>), dim3(grid), dim3(512), lds, st, P); break;
-        case 192: hipLaunchKernelGGL((k_tower<192, 4, 2, 128>), dim3(grid), dim3(512), lds, st, P); break;
+        case 192:
+            if (m->waves == 4) hipLaunchKernelGGL((k_tower<192, 2, 2, 128>), dim3(grid), dim3(256), lds, st, P);
+            else hipLaunchKernelGGL((k_tower<192, 4, 2, 128>), dim3(grid), dim3(512), lds, st, P);
+            break;
         default: return fail(AZ_ERR_ARG, "unsupported channel count");
     }
     if (ev) (void)hipEventRecord(ev->second, st);
