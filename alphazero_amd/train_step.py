@@ -1,0 +1,79 @@
+"""The training step of the upstream train_candidate (go_zero/train.py:504-554) as a reusable object,
+with data-parallel gradient averaging over torch.distributed (backend "nccl" = RCCL over xGMI on
+MI355X; "gloo" on CPU for tests). One process per GPU; the all-reduce is bucketed into one flat
+buffer (9.15 M parameters = 36.6 MB float32 for the 192x12 net: a single collective per step).
+
+Loss = soft-target cross entropy + Huber(value, z) - entropy_coeff * entropy, AdamW, cosine LR to
+0.1*lr, gradient clipping at max-norm 1.0 -- same formulas and order as upstream.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def loss_terms(logits, values, target_policies, target_values, huber_delta=1.0, entropy_coeff=1e-3):
+    """train.py:537-541 -> (loss, policy_loss, value_loss)."""
+    logp = F.log_softmax(logits, dim=1)
+    policy_loss = -(target_policies * logp).sum(dim=1).mean()
+    value_loss = F.huber_loss(values, target_values, delta=huber_delta)
+    entropy = -(F.softmax(logits, dim=1) * logp).sum(dim=1).mean()
+    return policy_loss + value_loss - entropy_coeff * entropy, policy_loss, value_loss
+
+
+class DataParallelTrainer:
+    def __init__(self, model, lr=1e-3, weight_decay=1e-4, total_steps=800, grad_clip_norm=1.0, huber_delta=1.0,
+                 entropy_coeff=1e-3, target_smoothing=0.0, use_amp=False, process_group=None):
+        self.model = model
+        self.opt = torch.optim.AdamW(model.parameters(), lr=lr, weight_decay=weight_decay)            # train.py:505
+        self.sched = torch.optim.lr_scheduler.CosineAnnealingLR(self.opt, T_max=max(1, total_steps), eta_min=lr * 0.1)
+        self.clip, self.delta, self.ent = grad_clip_norm, huber_delta, entropy_coeff
+        self.smooth = float(np.clip(target_smoothing, 0.0, 0.25))
+        dev = next(model.parameters()).device
+        self.amp = bool(use_amp and dev.type == "cuda")
+        self.scaler = torch.amp.GradScaler("cuda", enabled=self.amp)                                  # train.py:512-513
+        import torch.distributed as dist
+        self.dist = dist if (dist.is_available() and dist.is_initialized()) else None
+        self.group = process_group
+        self.world = self.dist.get_world_size(process_group) if self.dist else 1
+        self._flat = None
+        if self.dist:  # identical starting weights on every rank
+            for p in model.state_dict().values():
+                self.dist.broadcast(p.data if p.is_floating_point() else p, src=0, group=process_group)
+
+    def _allreduce_grads(self):
+        params = [p for p in self.model.parameters() if p.grad is not None]
+        if self._flat is None or self._flat.numel() != sum(p.numel() for p in params):
+            self._flat = torch.empty(sum(p.numel() for p in params), dtype=params[0].grad.dtype, device=params[0].device)
+        off = 0
+        for p in params:
+            n = p.numel()
+            self._flat[off:off + n].copy_(p.grad.reshape(-1))
+            off += n
+        self.dist.all_reduce(self._flat, op=self.dist.ReduceOp.SUM, group=self.group)
+        self._flat.div_(self.world)
+        off = 0
+        for p in params:
+            n = p.numel()
+            p.grad.copy_(self._flat[off:off + n].view_as(p.grad))
+            off += n
+
+    def step(self, states, target_policies, target_values):
+        """One optimisation step on this rank's shard of the global batch (train.py:526-548)."""
+        self.model.train()
+        if self.smooth > 0.0:
+            target_policies = target_policies * (1.0 - self.smooth) + (self.smooth / target_policies.shape[1])
+        self.opt.zero_grad(set_to_none=True)
+        with torch.autocast(device_type="cuda", enabled=self.amp):
+            logits, values = self.model(states)
+            loss, pl, vl = loss_terms(logits, values, target_policies, target_values, self.delta, self.ent)
+        self.scaler.scale(loss).backward()
+        self.scaler.unscale_(self.opt)
+        if self.dist and self.world > 1:
+            self._allreduce_grads()
+        torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.clip)
+        self.scaler.step(self.opt)
+        self.scaler.update()
+        self.sched.step()
+        return float(loss.item()), float(pl.item()), float(vl.item())

@@ -1,0 +1,121 @@
+"""World-size-2 checks on the gloo backend: (1) games shard over ranks with no data-path collective
+and per-game seeds make the union of the shards equal the single-rank run (host logic only, stub
+device), (2) the data-parallel training step averages gradients so that two ranks with half the
+batch each take the same step as one rank with the whole batch."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _train_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from alphazero_amd.model import AlphaZeroNet
+    from alphazero_amd.train_step import DataParallelTrainer
+    torch.manual_seed(100 + rank)                      # different init per rank: the trainer must broadcast rank 0's
+    net = AlphaZeroNet(board_size=5, channels=32, num_blocks=1, value_hidden_dim=32)
+    tr = DataParallelTrainer(net, lr=1e-2, total_steps=10)
+    g = torch.Generator().manual_seed(7)
+    x = (torch.rand((8, 21, 5, 5), generator=g) < 0.3).float()
+    pi = torch.softmax(torch.randn((8, 26), generator=g), 1)
+    z = torch.rand((8,), generator=g) * 2 - 1
+    sl = slice(rank * 4, rank * 4 + 4)
+    losses = [tr.step(x[sl], pi[sl], z[sl]) for _ in range(3)]
+    flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    if rank == 0:
+        torch.save({"flat": flat, "losses": losses}, out)
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    assert torch.equal(gathered[0], gathered[1]), "ranks diverged"
+    dist.destroy_process_group()
+
+
+def test_data_parallel_step_matches_single_process(tmp_path):
+    out = str(tmp_path / "dp.pt")
+    mp.spawn(_train_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out, weights_only=True)
+    sys.path.insert(0, ROOT)
+    from alphazero_amd.model import AlphaZeroNet
+    from alphazero_amd.train_step import DataParallelTrainer
+    torch.set_num_threads(1)
+    torch.manual_seed(100)
+    net = AlphaZeroNet(board_size=5, channels=32, num_blocks=1, value_hidden_dim=32)
+    net.eval()   # batch-norm batch statistics differ between a batch of 8 and two of 4: compare in eval-mode BN
+    tr = DataParallelTrainer(net, lr=1e-2, total_steps=10)
+    g = torch.Generator().manual_seed(7)
+    x = (torch.rand((8, 21, 5, 5), generator=g) < 0.3).float()
+    pi = torch.softmax(torch.randn((8, 26), generator=g), 1)
+    z = torch.rand((8,), generator=g) * 2 - 1
+    # reference: one process, whole batch, gradients of the two half-batch means averaged by hand
+    from alphazero_amd.train_step import loss_terms
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-2, weight_decay=1e-4)
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=10, eta_min=1e-3)
+    for _ in range(3):
+        net.train()
+        grads = None
+        for sl in (slice(0, 4), slice(4, 8)):
+            opt.zero_grad(set_to_none=True)
+            lg, v = net(x[sl])
+            loss, _, _ = loss_terms(lg, v, pi[sl], z[sl])
+            loss.backward()
+            gs = [p.grad.clone() for p in net.parameters()]
+            grads = gs if grads is None else [a + b for a, b in zip(grads, gs)]
+        # BN running stats were updated twice here and once per rank there; parameters are what we compare
+        for p, gsum in zip(net.parameters(), grads):
+            p.grad = gsum / 2
+        torch.nn.utils.clip_grad_norm_(net.parameters(), 1.0)
+        opt.step()
+        sched.step()
+    flat = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    assert torch.allclose(flat, got["flat"], atol=1e-6), float((flat - got["flat"]).abs().max())
+
+
+def _shard_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from alphazero_amd.selfplay import HostRng
+    G = 6                                   # games per rank; game id = rank * G + slot, seed = seed0 + id
+    rng = HostRng(G, threads=1)
+    for s in range(G):
+        rng.seed(s, 1000 + rank * G + s)
+    noise = rng.dirichlet(np.full(G, 26, np.int32), 0.3, 26)
+    u = rng.random_sample()
+    t = torch.from_numpy(np.concatenate([noise.reshape(-1), u]))
+    gathered = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(gathered, t)            # test-only collective: the data path itself has none
+    if rank == 0:
+        torch.save(torch.stack(gathered), out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_game_sharding_is_seeded_per_game(tmp_path):
+    out = str(tmp_path / "shard.pt")
+    mp.spawn(_shard_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = torch.load(out, weights_only=True).numpy()
+    for rank in range(2):
+        for s in range(6):
+            rs = np.random.RandomState(1000 + rank * 6 + s)
+            want = rs.dirichlet([0.3] * 26)
+            assert np.array_equal(got[rank][s * 26:(s + 1) * 26], want)
+            assert got[rank][6 * 26 + s] == rs.random_sample()

@@ -27,7 +27,8 @@ def test_state_dict_contract_and_outputs(name):
     assert net.board_size == kw["board_size"] and net.action_dim == kw["board_size"] ** 2 + 1
     with torch.inference_mode():
         lg, v = net(torch.from_numpy(x))
-    assert np.abs(lg.numpy() - z[f"{name}/logits"]).max() < 2e-5
+    scale = max(1.0, float(np.abs(z[f"{name}/logits"]).max()))   # float32 summation order varies with the thread count
+    assert np.abs(lg.numpy() - z[f"{name}/logits"]).max() < 1e-5 * scale
     assert np.abs(v.numpy() - z[f"{name}/value"]).max() < 2e-5
 
 
