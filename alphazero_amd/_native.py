@@ -49,6 +49,8 @@ SIGNATURES = {
     "az_mcts_begin": (_I32, [_VP, _VP, _VP]),
     "az_mcts_select": (_I32, [_VP, _VP]),
     "az_mcts_pending": (_I32, [_VP, C.POINTER(_I32), _VP]),
+    "az_mcts_set_async": (_I32, [_VP, _I32]),
+    "az_mcts_rows_device": (_I32, [_VP, C.POINTER(_VP)]),
     "az_mcts_gather": (_I32, [_VP, _VP, _I32, _VP]),
     "az_mcts_row_games": (_I32, [_VP, _VP, _VP]),
     "az_mcts_expand": (_I32, [_VP, _VP, _VP, _VP, _VP]),
@@ -61,6 +63,9 @@ SIGNATURES = {
     "az_net_param_count": (_I64, [_VP]),
     "az_net_load": (_I32, [_VP, _VP, _I64]),
     "az_net_forward": (_I32, [_VP, _VP, _I32, _VP, _VP, _VP]),
+    "az_net_forward_indirect": (_I32, [_VP, _VP, _VP, _I32, _VP, _VP, _VP]),
+    "az_net_profile_spans": (_I32, [_VP, _VP, C.c_int64, C.POINTER(C.c_int64)]),
+    "az_net_set_tower_workgroups": (_I32, [_VP, _I32]),
     "az_net_profile": (_I32, [_VP, _I32, C.POINTER(C.c_double), C.POINTER(_I64), C.POINTER(_I64)]),
     "az_rng_create": (_I32, [_I32, C.POINTER(_VP)]),
     "az_rng_destroy": (_I32, [_VP]),

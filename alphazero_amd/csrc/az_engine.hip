@@ -800,6 +800,7 @@ struct az_engine {
     int sims_done = 0, batch_n = 0;
     int pending_rows = 0;
     bool rows_known = false;
+    bool async_mode = false;        // never synchronise inside a search: grids sized by upper bounds
     int* ctl_host = nullptr;        // pinned
     long long* stats_host = nullptr;
     double* last_priors = nullptr;  // [max_rows][A]
@@ -1010,6 +1011,18 @@ int az_mcts_pending(az_engine* e, int32_t* rows_out, void* stream) {
     return AZ_OK;
 }
 
+int az_mcts_set_async(az_engine* e, int32_t enable) {
+    if (!e) return fail(AZ_ERR_ARG, "null engine");
+    e->async_mode = enable != 0;
+    return AZ_OK;
+}
+
+int az_mcts_rows_device(az_engine* e, const int32_t** rows_dev_out) {
+    if (!e || !rows_dev_out) return fail(AZ_ERR_ARG, "null argument");
+    *rows_dev_out = e->d.ctl;
+    return AZ_OK;
+}
+
 static int need_rows(az_engine* e, void* stream) {
     if (e->rows_known) return AZ_OK;
     int32_t r;
@@ -1020,11 +1033,17 @@ int az_mcts_gather(az_engine* e, void* out, int32_t layout, void* stream) {
     if (!e || !out) return fail(AZ_ERR_ARG, "null argument");
     if (e->phase != PH_ROOT && e->phase != PH_SELECTED) return fail(AZ_ERR_STATE, "az_mcts_gather: no pending rows");
     if (layout != AZ_FEAT_F32_NCHW && layout != AZ_FEAT_BF16_NHWC) return fail(AZ_ERR_ARG, "bad layout");
-    int rc = need_rows(e, stream);
-    if (rc != AZ_OK) return rc;
-    if (e->pending_rows == 0) return AZ_OK;
+    int grid;
+    if (e->async_mode && !e->rows_known) {
+        grid = e->phase == PH_ROOT ? e->d.G : e->d.max_rows;   // surplus waves see r >= rows and leave
+    } else {
+        int rc = need_rows(e, stream);
+        if (rc != AZ_OK) return rc;
+        grid = e->pending_rows;
+    }
+    if (grid == 0) return AZ_OK;
     const size_t shmem = seen_bytes(e) + (size_t)e->d.H * e->d.npad;
-    DISPATCH_PPL(e, k_leaf, e->pending_rows, shmem, stream, e->d, out, layout);
+    DISPATCH_PPL(e, k_leaf, grid, shmem, stream, e->d, out, layout);
     return check_launch("k_leaf");
 }
 
@@ -1043,9 +1062,13 @@ int az_mcts_expand(az_engine* e, const float* logits, const float* values, const
         if (!logits) return fail(AZ_ERR_ARG, "null logits");
         hipLaunchKernelGGL(k_expand_root, dim3(e->d.G), dim3(64), shmem, (hipStream_t)stream, e->d, logits, noise, e->last_priors);
     } else if (e->phase == PH_SELECTED) {
-        int rc = need_rows(e, stream);
-        if (rc != AZ_OK) return rc;
-        if (e->pending_rows > 0 && (!logits || !values)) return fail(AZ_ERR_ARG, "null logits/values");
+        if (!e->async_mode) {
+            int rc = need_rows(e, stream);
+            if (rc != AZ_OK) return rc;
+            if (e->pending_rows > 0 && (!logits || !values)) return fail(AZ_ERR_ARG, "null logits/values");
+        } else if (!logits || !values) {
+            return fail(AZ_ERR_ARG, "null logits/values");
+        }
         hipLaunchKernelGGL(k_expand_backup, dim3(e->d.G), dim3(64), shmem, (hipStream_t)stream, e->d, logits, values,
                            e->batch_n, e->last_priors);
         e->sims_done += e->batch_n;
@@ -1082,8 +1105,13 @@ int az_mcts_last_priors(az_engine* e, double* priors, void* stream) {
 int az_mcts_stats(az_engine* e, int64_t* out, void* stream) {
     if (!e || !out) return fail(AZ_ERR_ARG, "null argument");
     HIP_TRY(hipMemcpyAsync(e->stats_host, e->d.stats, 8 * sizeof(long long), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    if (e->async_mode) HIP_TRY(hipMemcpyAsync(e->ctl_host, e->d.ctl, 4 * sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     for (int i = 0; i < 8; ++i) out[i] = e->stats_host[i];
+    if (e->async_mode) {   // failures of the batches that were enqueued without a round trip surface here
+        if (e->ctl_host[1] == AZ_ERR_NOCHILD) return fail(AZ_ERR_NOCHILD, "No child selected in MCTS");
+        if (e->ctl_host[1] == AZ_ERR_CAPACITY) return fail(AZ_ERR_CAPACITY, "search tree node capacity exceeded");
+    }
     return AZ_OK;
 }
 

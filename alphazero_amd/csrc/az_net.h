@@ -31,6 +31,8 @@ int mfma_create(const az_net_config& c, const NetLayout& L, const float* params,
 void mfma_destroy(MfmaNet* m);
 void mfma_set_profiling(MfmaNet* m, bool on);
 int mfma_profile(MfmaNet* m, double* tower_ms, long long* launches, long long* rows);
-int mfma_forward(MfmaNet* m, const void* feat_bf16_nhwc, int rows, float* logits, float* values, hipStream_t st);
+int mfma_profile_spans(MfmaNet* m, double* spans, long long cap, long long* count);
+int mfma_set_grid_limit(MfmaNet* m, int workgroups);
+int mfma_forward(MfmaNet* m, const void* feat_bf16_nhwc, int rows, const int* rows_dev, float* logits, float* values, hipStream_t st);
 
 }  // namespace az

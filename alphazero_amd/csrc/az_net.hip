@@ -274,6 +274,21 @@ static int ensure_scratch(az_net* net, int rows) {
     return AZ_OK;
 }
 
+int az_net_profile_spans(az_net* net, double* spans_ms, int64_t capacity, int64_t* count) {
+    if (!net || !count || (capacity > 0 && !spans_ms)) return fail(AZ_ERR_ARG, "null argument");
+    if (net->cfg.precision != AZ_NET_BF16 || !net->mfma) return fail(AZ_ERR_STATE, "az_net_profile_spans: bf16 network not loaded");
+    long long n = 0;
+    int rc = mfma_profile_spans(net->mfma, spans_ms, capacity, &n);
+    *count = n;
+    return rc;
+}
+
+int az_net_set_tower_workgroups(az_net* net, int32_t workgroups) {
+    if (!net) return fail(AZ_ERR_ARG, "null network");
+    if (net->cfg.precision != AZ_NET_BF16 || !net->mfma) return fail(AZ_ERR_STATE, "az_net_set_tower_workgroups: bf16 network not loaded");
+    return mfma_set_grid_limit(net->mfma, workgroups);
+}
+
 int az_net_profile(az_net* net, int32_t enable, double* tower_ms, int64_t* launches, int64_t* rows) {
     if (!net) return fail(AZ_ERR_ARG, "null network");
     if (net->cfg.precision != AZ_NET_BF16 || !net->mfma) return fail(AZ_ERR_STATE, "az_net_profile: bf16 network not loaded");
@@ -288,13 +303,22 @@ int az_net_profile(az_net* net, int32_t enable, double* tower_ms, int64_t* launc
     return AZ_OK;
 }
 
+int az_net_forward_indirect(az_net* net, const void* feat, const int32_t* rows_dev, int32_t max_rows, float* logits, float* values,
+                            void* stream_) {
+    if (!net || !feat || !rows_dev || !logits || !values) return fail(AZ_ERR_ARG, "null argument");
+    if (!net->loaded) return fail(AZ_ERR_STATE, "az_net_forward_indirect before az_net_load");
+    if (net->cfg.precision != AZ_NET_BF16) return fail(AZ_ERR_ARG, "az_net_forward_indirect: bf16 networks only");
+    if (max_rows <= 0) return AZ_OK;
+    return mfma_forward(net->mfma, feat, max_rows, rows_dev, logits, values, (hipStream_t)stream_);
+}
+
 int az_net_forward(az_net* net, const void* feat, int32_t rows, float* logits, float* values, void* stream_) {
     if (!net || !feat || !logits || !values) return fail(AZ_ERR_ARG, "null argument");
     if (!net->loaded) return fail(AZ_ERR_STATE, "az_net_forward before az_net_load");
     if (rows <= 0) return AZ_OK;
     hipStream_t st = (hipStream_t)stream_;
     const az_net_config& c = net->cfg;
-    if (c.precision == AZ_NET_BF16) return mfma_forward(net->mfma, feat, rows, logits, values, st);
+    if (c.precision == AZ_NET_BF16) return mfma_forward(net->mfma, feat, rows, nullptr, logits, values, st);
     int rc = ensure_scratch(net, rows);
     if (rc != AZ_OK) return rc;
     const int n = c.board_size, np = n * n, C = c.channels, q = C / 4, A = np + 1, T = 256;

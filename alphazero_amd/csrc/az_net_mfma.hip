@@ -49,6 +49,7 @@ struct TowerParams {
     uint16_t* hq;                // out: [rows][np][2q] bf16, relu(bn(conv1x1)) of both heads
     uint4* xres;                 // residual stream scratch: [gridDim.x][MI*NI*2][threads] 16-byte vectors, private per thread
     int items;                   // board groups (of TB boards) to process; workgroups stride over them
+    const int* rows_dev;         // if set, the row count is read here (rows is then an upper bound)
     unsigned long long* stamps;  // diagnostic build (-DAZ_STAMP) only: per-workgroup phase cycle sums
 };
 
@@ -139,6 +140,10 @@ __device__ __forceinline__ void gemm_taps(f32x16 (&acc)[MI][NI], const uint4* __
     __syncthreads();
     for (int t = 0; t < ntiles; ++t) {
         const char* cur = bbuf + (t & 1) * tile_bytes;
+#ifdef AZ_DIAG_SAMETILE
+        if (t + 1 < ntiles) stage_tile<NW>(wg, bbuf + ((t + 1) & 1) * tile_bytes, nvec, lane, wave);
+        else
+#endif
         if (t + 1 < ntiles) stage_tile<NW>(wg + (size_t)(t + 1) * nvec, bbuf + ((t + 1) & 1) * tile_bytes, nvec, lane, wave);
         const int tap = t / tiles_per_tap, c0 = (t - tap * tiles_per_tap) * KT;
         const int dy = three ? tap / 3 - 1 : 0, dx = three ? tap - (tap / 3) * 3 - 1 : 0;
@@ -234,7 +239,11 @@ __device__ __forceinline__ void store_act(const f32x16 (&acc)[MI][NI], const flo
 // in act; pooled/hidden/scale and the block's SE weights live in `scratch` (the idle weight buffers).
 template <int MI, int NI, int WM, int WN, int C, int STRIDE>
 __device__ __forceinline__ void se_gate(f32x16 (&acc)[MI][NI], const char* act, float* scratch, const uint4* __restrict__ blob, int se_vecs,
-                                        int hid, int TB, int nb, const TileGeo& g) {
+                                        int hid, int TB, int nb, const TileGeo& g
+#ifdef AZ_STAMP
+                                        , unsigned long long* stamp_acc, unsigned long long& stamp_last
+#endif
+                                        ) {
     constexpr int NW = WM * WN, NT = 64 * NW;
     AZ_LANE_GEO(NI);
     const int NP = g.np;
@@ -270,8 +279,10 @@ __device__ __forceinline__ void se_gate(f32x16 (&acc)[MI][NI], const char* act, 
         pooled[b * C + 2 * cp] = s0 * inv_np;
         pooled[b * C + 2 * cp + 1] = s1 * inv_np;
     }
+    STAMP(8);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // SE weights have landed
     __syncthreads();
+    STAMP(9);
     {   // fc1 + relu: 8 lanes per output, fixed reduction tree
         const int sub = t_ & 7;
         for (int o = t_ >> 3; o < nb * hid; o += NT / 8) {
@@ -286,6 +297,7 @@ __device__ __forceinline__ void se_gate(f32x16 (&acc)[MI][NI], const char* act, 
         }
     }
     __syncthreads();
+    STAMP(10);
     for (int i = t_; i < nb * C; i += NT) {   // fc2 + sigmoid
         const int b = i / C, ch = i - b * C;
         float s = b2[ch];
@@ -301,6 +313,7 @@ __device__ __forceinline__ void se_gate(f32x16 (&acc)[MI][NI], const char* act, 
         sc[i] = 1.f / (1.f + __expf(-s));
     }
     __syncthreads();
+    STAMP(11);
     // A 32-row MFMA tile covers at most two boards when a board has >= 32 points: rows below
     // `split` belong to board bA, the others to bA + 1.
     if (NP >= 32) {
@@ -393,15 +406,17 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_tower(TowerPara
     const int tid = threadIdx.x;
     uint4* xres_wg = P.xres + (size_t)blockIdx.x * NV * NT;
 #ifdef AZ_STAMP
-    unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last;
+    unsigned long long stamp_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_last;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
 #endif
     for (int i = tid; i < STRIDE / 4; i += NT) ((uint32_t*)zrow)[i] = 0;
     TileGeo g;
     g.n = P.n; g.np = P.np; g.recip_np = P.recip_np; g.recip_n = P.recip_n;
-    for (int item = blockIdx.x; item < P.items; item += gridDim.x) {
+    const int rows = P.rows_dev ? min(*P.rows_dev, P.rows) : P.rows;
+    const int items = (rows + P.TB - 1) / P.TB;
+    for (int item = blockIdx.x; item < items; item += gridDim.x) {
         const int board0 = item * P.TB;
-        const int nb = min(P.TB, P.rows - board0);
+        const int nb = min(P.TB, rows - board0);
         g.vrows = nb * P.np;  // valid rows of this workgroup
         __syncthreads();      // the previous item's last LDS reads are done
 
@@ -460,7 +475,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_tower(TowerPara
             }
             if (P.use_se) {
                 store_act<MI, NI, WM, WN, STRIDE, false, false>(acc, nullptr, act, xres_wg);   // bf16 image of y for the pooling
+                STAMP(7);
+#ifdef AZ_STAMP
+                se_gate<MI, NI, WM, WN, C, STRIDE>(acc, act, scratch, P.se_blob + (size_t)blk * P.se_vecs, P.se_vecs, P.hid, P.TB, nb, g, stamp_acc, stamp_last);
+#else
                 se_gate<MI, NI, WM, WN, C, STRIDE>(acc, act, scratch, P.se_blob + (size_t)blk * P.se_vecs, P.se_vecs, P.hid, P.TB, nb, g);
+#endif
             }
             STAMP(4);
             residual_store<MI, NI, WM, WN, STRIDE>(acc, resv, act, xres_wg, blk + 1 < P.blocks);
@@ -500,16 +520,17 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_tower(TowerPara
     }  // item loop
 #ifdef AZ_STAMP
     if (tid == 0 && P.stamps)
-        for (int i = 0; i < 8; ++i) P.stamps[(size_t)blockIdx.x * 8 + i] = stamp_acc[i];
+        for (int i = 0; i < 16; ++i) P.stamps[(size_t)blockIdx.x * 16 + i] = stamp_acc[i];
 #endif
 }
 
 // Policy tail (model.py:72-76, :93-94): 1x1 conv q->2 + BN + ReLU, flatten channel-major, linear.
 __global__ __launch_bounds__(128) void k_policy_tail(const uint16_t* __restrict__ hq, const float* __restrict__ w3, const float* __restrict__ b3,
                                                      const float* __restrict__ wfcT, const float* __restrict__ bfc, float* __restrict__ logits,
-                                                     int np, int q) {
+                                                     int np, int q, const int* rows_dev) {
     extern __shared__ float flat[];  // [2*np]
     const int r = blockIdx.x, A = np + 1, q2 = 2 * q;
+    if (rows_dev && r >= *rows_dev) return;
     for (int i = threadIdx.x; i < 2 * np; i += blockDim.x) {
         const int c2 = i / np, pos = i - c2 * np;
         const uint16_t* src = hq + ((size_t)r * np + pos) * q2;
@@ -529,9 +550,11 @@ __global__ __launch_bounds__(128) void k_policy_tail(const uint16_t* __restrict_
 template <int RB>
 __global__ __launch_bounds__(256) void k_value_tail(const uint16_t* __restrict__ hq, const uint16_t* __restrict__ w4T, const float* __restrict__ b4,
                                                     const float* __restrict__ w6, const float* __restrict__ b6, float* __restrict__ values,
-                                                    int rows, int np, int q, int vh) {
+                                                    int rows, int np, int q, int vh, const int* rows_dev) {
     extern __shared__ float v0[];  // [RB][q*np] then [RB][vh]
+    if (rows_dev) rows = min(rows, *rows_dev);
     const int r0 = blockIdx.x * RB, nbk = min(RB, rows - r0), K = q * np, q2 = 2 * q;
+    if (nbk <= 0) return;
     float* hid = v0 + RB * K;
     for (int i = threadIdx.x; i < RB * K; i += blockDim.x) {
         const int b = i / K, k = i - b * K, ch = k / np, pos = k - ch * np;
@@ -758,7 +781,53 @@ int mfma_create(const az_net_config& c, const NetLayout& L, const float* Pm, Mfm
     return AZ_OK;
 }
 
+// One reference event per device: launch spans of different networks and streams share its time line.
+static hipEvent_t g_base_event[64];
+static bool g_base_set[64];
+
+static int base_event(int device, hipEvent_t* out) {
+    if (device < 0 || device >= 64) return fail(AZ_ERR_ARG, "device index out of range");
+    if (!g_base_set[device]) {
+        if (hipEventCreate(&g_base_event[device]) != hipSuccess || hipEventRecord(g_base_event[device], nullptr) != hipSuccess ||
+            hipEventSynchronize(g_base_event[device]) != hipSuccess)
+            return fail(AZ_ERR_HIP, "profiling base event");
+        g_base_set[device] = true;
+    }
+    *out = g_base_event[device];
+    return AZ_OK;
+}
+
+int mfma_set_grid_limit(MfmaNet* m, int workgroups) {
+    if (workgroups < 1) return fail(AZ_ERR_ARG, "workgroup limit must be >= 1");
+    if (workgroups == m->max_grid) return AZ_OK;
+    if (hipDeviceSynchronize() != hipSuccess) return fail(AZ_ERR_HIP, "hipDeviceSynchronize");
+    uint4* x = nullptr;
+    if (hipMalloc((void**)&x, (size_t)workgroups * 256 * (size_t)m->cfg.channels * 2) != hipSuccess) return fail(AZ_ERR_HIP, "hipMalloc (residual scratch)");
+    if (m->xres) (void)hipFree(m->xres);
+    m->xres = x;
+    m->max_grid = workgroups;
+    return AZ_OK;
+}
+
+int mfma_profile_spans(MfmaNet* m, double* spans, long long cap, long long* count) {
+    hipEvent_t base;
+    int rc = base_event(m->cfg.device, &base);
+    if (rc != AZ_OK) return rc;
+    long long n = 0;
+    for (size_t i = 0; i < m->ev_used && n < cap; ++i, ++n) {
+        if (hipEventSynchronize(m->events[i].second) != hipSuccess) return fail(AZ_ERR_HIP, "hipEventSynchronize");
+        float a = 0.f, b = 0.f;
+        if (hipEventElapsedTime(&a, base, m->events[i].first) != hipSuccess || hipEventElapsedTime(&b, base, m->events[i].second) != hipSuccess)
+            return fail(AZ_ERR_HIP, "hipEventElapsedTime");
+        spans[2 * n] = a;
+        spans[2 * n + 1] = b;
+    }
+    *count = (long long)m->ev_used;
+    return AZ_OK;
+}
+
 void mfma_set_profiling(MfmaNet* m, bool on) {
+    if (on) { hipEvent_t b; (void)base_event(m->cfg.device, &b); }
     m->profiling = on;
     m->ev_used = 0;
     m->prof_rows = 0;
@@ -791,7 +860,7 @@ void mfma_destroy(MfmaNet* m) {
     delete m;
 }
 
-int mfma_forward(MfmaNet* m, const void* feat, int rows, float* logits, float* values, hipStream_t st) {
+int mfma_forward(MfmaNet* m, const void* feat, int rows, const int* rows_dev, float* logits, float* values, hipStream_t st) {
     const az_net_config& c = m->cfg;
     const int C = c.channels, np = c.board_size * c.board_size, q = m->q;
     if (rows > m->hq_rows) {  // scratch for the head activations grows outside the steady state
@@ -809,13 +878,14 @@ int mfma_forward(MfmaNet* m, const void* feat, int rows, float* logits, float* v
     P.stamps = nullptr;
     P.xres = m->xres;
     P.items = (rows + m->TB - 1) / m->TB;
+    P.rows_dev = rows_dev;
     const int grid = std::min(P.items, m->max_grid);
 #ifdef AZ_STAMP
     static unsigned long long* stamp_dev = nullptr;
     static int stamp_grid = 0;
     if (grid > stamp_grid) {
         if (stamp_dev) (void)hipFree(stamp_dev);
-        (void)hipMalloc((void**)&stamp_dev, (size_t)grid * 64);
+        (void)hipMalloc((void**)&stamp_dev, (size_t)grid * 128);
         stamp_grid = grid;
     }
     P.stamps = stamp_dev;
@@ -829,7 +899,7 @@ int mfma_forward(MfmaNet* m, const void* feat, int rows, float* logits, float* v
             m->events.emplace_back(a, b);
         }
         ev = &m->events[m->ev_used++];
-        m->prof_rows += rows;
+        m->prof_rows += rows_dev ? 0 : rows;   // indirect launches: the caller knows the row total
         (void)hipEventRecord(ev->first, st);
     }
     switch (C) {
@@ -843,23 +913,24 @@ int mfma_forward(MfmaNet* m, const void* feat, int rows, float* logits, float* v
         default: return fail(AZ_ERR_ARG, "unsupported channel count");
     }
     if (ev) (void)hipEventRecord(ev->second, st);
-    hipLaunchKernelGGL(k_policy_tail, dim3(rows), dim3(128), (size_t)2 * np * 4, st, m->hq, m->w3, m->b3, m->wfcT, m->bfc, logits, np, q);
+    hipLaunchKernelGGL(k_policy_tail, dim3(rows), dim3(128), (size_t)2 * np * 4, st, m->hq, m->w3, m->b3, m->wfcT, m->bfc, logits, np, q, rows_dev);
     const size_t vt = ((size_t)4 * q * np + 4 * c.value_hidden) * 4;
     hipLaunchKernelGGL((k_value_tail<4>), dim3((rows + 3) / 4), dim3(256), vt, st, m->hq, m->w4T, m->b4, m->w6, m->b6, values, rows, np, q,
-                       c.value_hidden);
+                       c.value_hidden, rows_dev);
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return fail(AZ_ERR_HIP, std::string("bf16 forward: ") + hipGetErrorString(err));
 #ifdef AZ_STAMP
     {   // diagnostic build: print where a workgroup's cycles go (mean over workgroups)
-        std::vector<unsigned long long> hst((size_t)grid * 8);
+        std::vector<unsigned long long> hst((size_t)grid * 16);
         (void)hipDeviceSynchronize();
         (void)hipMemcpy(hst.data(), P.stamps, hst.size() * 8, hipMemcpyDeviceToHost);
-        double sum[8] = {0};
-        for (int g = 0; g < grid; ++g) for (int i = 0; i < 8; ++i) sum[i] += (double)hst[(size_t)g * 8 + i];
-        const char* nm[8] = {"load+stem gemm", "stem epilogue", "conv gemm (2/blk)", "conv1 epilogue", "SE (pool+fc+scale)", "residual epilogue", "head gemm+store", "-"};
-        double tot = 0; for (int i = 0; i < 7; ++i) tot += sum[i];
+        double sum[16] = {0};
+        for (int g = 0; g < grid; ++g) for (int i = 0; i < 16; ++i) sum[i] += (double)hst[(size_t)g * 16 + i];
+        const char* nm[16] = {"load+stem gemm", "stem epilogue", "conv gemm (2/blk)", "conv1 epilogue", "SE scale", "residual epilogue", "head gemm+store",
+                              "resv issue+bias+y image", "SE pooling", "SE wait+sync", "SE fc1", "SE fc2", "-", "-", "-", "-"};
+        double tot = 0; for (int i = 0; i < 12; ++i) tot += sum[i];
         fprintf(stderr, "[AZ_STAMP] rows=%d grid=%d mean cycles/WG=%.0f\n", rows, grid, tot / grid);
-        for (int i = 0; i < 7; ++i) fprintf(stderr, "  %-20s %10.0f  %5.1f%%\n", nm[i], sum[i] / grid, 100.0 * sum[i] / tot);
+        for (int i = 0; i < 12; ++i) fprintf(stderr, "  %-20s %10.0f  %5.1f%%\n", nm[i], sum[i] / grid, 100.0 * sum[i] / tot);
     }
 #endif
     return AZ_OK;

@@ -132,6 +132,16 @@ class Engine:
         N.check(self.L.az_mcts_pending(self._h, C.byref(r), _stream()), "az_mcts_pending")
         return r.value
 
+    def set_async(self, enable: bool):
+        """Asynchronous mode: gather/expand never wait for the device (see az_mcts_set_async)."""
+        N.check(self.L.az_mcts_set_async(self._h, 1 if enable else 0), "az_mcts_set_async")
+
+    def rows_device(self) -> int:
+        """Device address of the pending-row count (int32)."""
+        p = C.c_void_p()
+        N.check(self.L.az_mcts_rows_device(self._h, C.byref(p)), "az_mcts_rows_device")
+        return p.value
+
     def gather(self, rows: int, layout=N.AZ_FEAT_F32_NCHW, out=None):
         if out is None:
             if layout == N.AZ_FEAT_F32_NCHW:

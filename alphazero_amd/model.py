@@ -88,15 +88,18 @@ class AlphaZeroNet(nn.Module):
     def _fingerprint(self):
         return tuple(int(v._version) for v in self.state_dict(keep_vars=True).values())
 
-    def native(self, precision: str = "bf16", device=None) -> "NativeNet":
+    def native(self, precision: str = "bf16", device=None, shared: bool = True) -> "NativeNet":
         """HIP inference engine holding a (BN-folded) copy of the current weights; rebuilt when a
-        parameter tensor has been modified in place or replaced since the last call."""
+        parameter tensor has been modified in place or replaced since the last call. shared=False
+        returns a private handle (own activation scratch) for a caller that runs it on its own stream."""
         if device is None:
             device = next(self.parameters()).device
         device = torch.device(device)
         if device.type != "cuda":
             raise N.NativeError("native inference needs the model on a GPU (no CPU fallback)")
         key = (precision, device.index if device.index is not None else torch.cuda.current_device())
+        if not shared:
+            return NativeNet(self._hyper, self.flat_parameters(), precision, key[1])
         fp = self._fingerprint()
         ent = self._native.get(key)
         if ent is None or ent[0] != fp:
@@ -164,6 +167,29 @@ class NativeNet:
         return logits, values
 
     __call__ = forward
+
+    def forward_indirect(self, feats: torch.Tensor, rows_dev: int, max_rows: int, logits: torch.Tensor, values: torch.Tensor):
+        """bf16 forward of the first *rows_dev rows (an int32 in device memory, <= max_rows) into the given
+        float32 buffers [max_rows, A] / [max_rows]; nothing waits for the device."""
+        assert feats.dtype == torch.bfloat16 and feats.is_contiguous() and feats.shape[0] >= max_rows
+        assert logits.dtype == torch.float32 and logits.is_contiguous() and logits.shape[0] >= max_rows
+        assert values.dtype == torch.float32 and values.is_contiguous() and values.shape[0] >= max_rows
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        N.check(self.L.az_net_forward_indirect(self._h, C.c_void_p(feats.data_ptr()), C.c_void_p(rows_dev), max_rows,
+                                               C.c_void_p(logits.data_ptr()), C.c_void_p(values.data_ptr()), st),
+                "az_net_forward_indirect")
+
+    def set_tower_workgroups(self, workgroups: int):
+        N.check(self.L.az_net_set_tower_workgroups(self._h, int(workgroups)), "az_net_set_tower_workgroups")
+
+    def profile_spans(self) -> np.ndarray:
+        """[launches, 2] start/end ms of the timed tower launches (device-wide time line); call before
+        profile(..., read=True), which clears them."""
+        n = C.c_int64()
+        N.check(self.L.az_net_profile_spans(self._h, None, 0, C.byref(n)), "az_net_profile_spans")
+        out = np.zeros((max(1, n.value), 2), np.float64)
+        N.check(self.L.az_net_profile_spans(self._h, out.ctypes.data_as(C.c_void_p), n.value, C.byref(n)), "az_net_profile_spans")
+        return out[: n.value]
 
     def profile(self, enable: bool, read: bool = False):
         """Switch HIP-event timing of the tower kernel on/off; with read=True first return

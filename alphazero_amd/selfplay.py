@@ -91,7 +91,7 @@ def policy_from_visits(visits: np.ndarray, temps: np.ndarray) -> np.ndarray:
             p[np.arange(len(rows)), np.argmax(v, axis=1)] = 1.0
         else:
             p = np.power(v, 1.0 / t)
-            s = np.array([row.sum() for row in p])      # 1-D sums: NumPy's pairwise order, as upstream
+            s = p.sum(axis=1)      # contiguous rows: the same pairwise order as the 1-D sums upstream takes
             bad = s <= 0
             p = np.where(bad[:, None], 1.0 / v.shape[1], p / np.where(bad, 1.0, s)[:, None])
         pi[rows] = p
@@ -106,148 +106,266 @@ def sample_actions(pi: np.ndarray, u: np.ndarray) -> np.ndarray:
     return (cdf <= u[:, None]).sum(axis=1).astype(np.int32)
 
 
+class _Lane:
+    """A share of the lockstep games with its own engine, network handle, HIP stream and random streams.
+    launch() enqueues one move's search without waiting for its batches; finish() collects it, picks the
+    moves and plays them. While one lane's host work runs, the other lanes' kernels keep the GPU busy."""
+
+    def __init__(self, owner, index, games, model, precision, dedup_leaves, rng_threads, own_stream):
+        cfg = owner.cfg
+        self.o, self.index, self.G = owner, index, int(games)
+        self.dev = owner.dev
+        self.stream = torch.cuda.Stream(device=self.dev) if own_stream else torch.cuda.current_stream(self.dev)
+        with torch.cuda.stream(self.stream):
+            self.eng = Engine(board_size=cfg.board_size, history_len=cfg.history_len, games=self.G, komi=cfg.komi,
+                              num_simulations=cfg.mcts_simulations, c_base=cfg.c_base, c_init=cfg.c_init,
+                              dirichlet_alpha=cfg.dirichlet_alpha, dirichlet_eps=cfg.dirichlet_eps,
+                              inference_batch_size=cfg.mcts_inference_batch, topk_expand=cfg.mcts_topk_expand,
+                              virtual_loss=cfg.mcts_virtual_loss, dedup_leaves=dedup_leaves, device=self.dev)
+            if hasattr(model, "native"):
+                self.net = model.native(precision, self.dev, shared=not own_stream)
+                self.layout = self.net.layout
+                self.eval = self.net.forward
+            else:  # plain callable on device tensors: feats f32 NCHW -> (logits, values)
+                self.net, self.layout, self.eval = None, N.AZ_FEAT_F32_NCHW, model
+            self.rng = HostRng(self.G, rng_threads)
+            self.A = self.eng.A
+            self.max_rows = self.eng.max_rows
+            if self.layout == N.AZ_FEAT_BF16_NHWC:
+                self.feat_buf = torch.empty((self.max_rows, cfg.board_size ** 2, self.eng.cpad), dtype=torch.bfloat16, device=self.dev)
+            else:
+                self.feat_buf = torch.empty((self.max_rows, self.eng.Cp, cfg.board_size, cfg.board_size), dtype=torch.float32, device=self.dev)
+            # with the native bf16 network the batches of a search are enqueued without host round trips
+            self.async_search = self.net is not None and precision == "bf16"
+            if self.async_search:
+                self.eng.set_async(True)
+                self.rows_dev = self.eng.rows_device()
+                self.logits_buf = torch.empty((self.max_rows, self.A), dtype=torch.float32, device=self.dev)
+                self.values_buf = torch.empty((self.max_rows,), dtype=torch.float32, device=self.dev)
+            self._bitw = torch.tensor([128, 64, 32, 16, 8, 4, 2, 1], dtype=torch.int32, device=self.dev)
+        self.step_no = 0
+        self.inflight = None
+
+    # ------------------------------------------------------------------ slots
+    def begin(self):
+        G = self.G
+        self.game_id = np.full(G, -1, np.int64)
+        self.move_idx = np.zeros(G, np.int64)
+        with torch.cuda.stream(self.stream):
+            self.eng.reset()
+        for s in range(G):
+            gid = self.o._deal()
+            if gid < 0:
+                break
+            self.game_id[s] = gid
+            self.rng.seed(s, self.o.seed0 + gid)
+        self.log = []                        # per step: (packed planes [G,*] u8, capf [G,2], pi f32 [G,A], to_play [G], difficulty [G])
+        self.log_base = self.step_no         # step index of log[0]
+        self.start_step = np.full(G, self.step_no, np.int64)   # first step of the game in each slot
+        self.inflight = None
+
+    def busy(self) -> bool:
+        return self.inflight is not None or bool((self.game_id >= 0).any())
+
+    # ------------------------------------------------------------------ one move, first half: enqueue the search
+    def launch(self):
+        active = self.game_id >= 0
+        if not active.any():
+            return
+        eng, c, cfg = self.eng, self.o.counters, self.o.cfg
+        with torch.cuda.stream(self.stream):
+            _, info = eng.status()
+            packed = self._pack_planes(eng.features(N.AZ_FEAT_F32_NCHW)) if self.o.collect else None
+            eng.search_begin(torch.from_numpy(active.astype(np.uint8)))
+            rows = eng.pending()
+            to_play = info.cpu().numpy()[:, 0].copy()
+            if rows == 0:
+                raise N.NativeError("search with no root to evaluate")
+            feats = eng.gather(rows, self.layout, out=self.feat_buf)
+            logits, values = self.eval(feats[:rows])
+            counts = eng.root_legal_counts().cpu().numpy()
+            t0 = time.perf_counter()
+            noise = self.rng.dirichlet(counts, cfg.dirichlet_alpha, self.A)
+            c["t_host_rng"] += time.perf_counter() - t0
+            done = eng.expand(logits, values, torch.from_numpy(noise))
+            c["nn_rows"] += rows
+            c["nn_rows_nodedup"] += rows
+            while not done and self.async_search:
+                eng.search_select()
+                eng.gather(self.max_rows, self.layout, out=self.feat_buf)
+                self.net.forward_indirect(self.feat_buf, self.rows_dev, self.max_rows, self.logits_buf, self.values_buf)
+                done = eng.expand(self.logits_buf, self.values_buf)
+            while not done:
+                eng.search_select()
+                rows = eng.pending()
+                if rows > 0:
+                    feats = eng.gather(rows, self.layout, out=self.feat_buf)
+                    logits, values = self.eval(feats[:rows])
+                    done = eng.expand(logits, values)
+                    c["nn_rows"] += rows
+                else:
+                    done = eng.expand(None, None)
+            visits, rv = eng.result()
+        self.inflight = (active, to_play, packed, visits, rv)
+
+    # ------------------------------------------------------------------ one move, second half (train.py:322-343)
+    def finish(self):
+        if self.inflight is None:
+            return
+        active, to_play, packed, visits, rv = self.inflight
+        self.inflight = None
+        o, cfg, G, eng, A = self.o, self.o.cfg, self.G, self.eng, self.A
+        c = o.counters
+        game_id, move_idx = self.game_id, self.move_idx
+        with torch.cuda.stream(self.stream):
+            st = eng.stats()
+            if self.async_search:
+                c["nn_rows"] += st["rows"]
+            c["sims"] += st["sims"]
+            c["nn_rows_nodedup"] += st["rows_raw"]
+            c["depth_sum"] += st["depth_sum"]
+            visits, rv = visits.cpu().numpy(), rv.cpu().numpy()
+            t0 = time.perf_counter()
+            temps = np.where(move_idx < cfg.temp_moves, cfg.temp_start,
+                             np.where(move_idx < cfg.temp_mid_moves, cfg.temp_mid, cfg.temp_end)).astype(np.float64)
+            act_rows = np.nonzero(active)[0]
+            pi = np.zeros((G, A), np.float64)
+            pi[act_rows] = policy_from_visits(visits[act_rows].astype(np.float64), temps[act_rows])
+            u = self.rng.random_sample(active)
+            actions = np.full(G, -1, np.int32)
+            actions[act_rows] = sample_actions(pi[act_rows], u[act_rows])
+            pi32 = pi.astype(np.float32)
+            c["t_host_policy"] += time.perf_counter() - t0
+            t0 = time.perf_counter()
+            if o.collect:
+                bits, caps = packed
+                diff = np.maximum(0.01, 1.0 - pi32.max(axis=1).astype(np.float64))      # train.py:336-337
+                self.log.append((bits.cpu().numpy(), caps.cpu().numpy(), pi32, to_play, diff))
+            c["t_samples"] += time.perf_counter() - t0
+            # resignation (train.py:339-341) ends the game before the move is played
+            resigned = np.zeros(G, np.int64)
+            if not cfg.disable_resign:
+                rs = active & (np.abs(rv) >= cfg.resign_threshold) & (move_idx >= 12)
+                resigned[rs] = np.where(rv[rs] < 0, -to_play[rs], to_play[rs])
+            actions[resigned != 0] = -1
+            eng.play(torch.from_numpy(actions))
+            move_idx[active & (resigned == 0)] += 1
+            c["moves"] += int(active.sum())
+            _, info = eng.status()
+            info = info.cpu().numpy()
+            over = active & ((info[:, 6] != 0) | (resigned != 0))
+            if over.any():
+                reset = np.zeros(G, np.uint8)
+                for s in np.nonzero(over)[0]:
+                    winner = int(resigned[s]) if resigned[s] != 0 else int(info[s, 7])
+                    o.results[0 if winner == 1 else (1 if winner == -1 else 2)] += 1
+                    o.finished[int(game_id[s])] = (self.index, int(s), int(self.start_step[s]), self.step_no + 1, winner)
+                    self.start_step[s] = self.step_no + 1
+                    c["games"] += 1
+                    move_idx[s] = 0
+                    gid = o._deal()
+                    game_id[s] = gid
+                    if gid >= 0:
+                        self.rng.seed(s, o.seed0 + gid)
+                        reset[s] = 1
+                if reset.any():
+                    eng.reset(torch.from_numpy(reset))
+        self.step_no += 1
+
+    def _pack_planes(self, planes):
+        """Binary planes of to_tensor() (go.py:265-304: all but the two capture planes) as np.packbits would
+        pack them (row-major, most significant bit first), packed on the device before the copy to the host."""
+        G, H = self.G, self.o.cfg.history_len
+        b = (planes[:, : 2 * H + 3].reshape(G, -1) > 0.5).to(torch.int32)
+        pad = (-b.shape[1]) % 8
+        if pad:
+            b = torch.nn.functional.pad(b, (0, pad))
+        bits = (b.view(G, -1, 8) * self._bitw).sum(-1).to(torch.uint8)
+        caps = planes[:, 2 * H + 3:, 0, 0].contiguous()
+        return bits, caps
+
+    def prune_log(self):
+        running = self.game_id >= 0
+        keep_from = int(self.start_step[running].min()) if running.any() else self.step_no
+        drop = max(0, keep_from - self.log_base)
+        del self.log[:drop]
+        self.log_base += drop
+
+
 class BatchedSelfPlay:
+    """`games` lockstep self-play games on one GPU, split over `lanes` independent lanes (engine + network
+    handle + HIP stream each). With one lane, step() plays one move of every game and returns. With more,
+    step() is software-pipelined: for each lane in turn it finishes the move enqueued by the previous step()
+    and enqueues the next search, so the lanes' kernels overlap each other and the host work; flush()
+    completes what is in flight. A game's trajectory depends only on its id (seed0 + id seeds its random
+    stream), not on the lane or slot that plays it."""
+
     def __init__(self, model, cfg: SelfPlayConfig, games: int, seed0: int = 0, dedup_leaves: bool = True,
-                 precision: str = "bf16", collect_samples: bool = True, device=None, rng_threads: int = 8):
+                 precision: str = "bf16", collect_samples: bool = True, device=None, rng_threads: int = 8,
+                 lanes: int = 1, tower_workgroups: int | None = None):
         self.cfg, self.G, self.seed0 = cfg, int(games), int(seed0)
         self.collect = collect_samples
         self.dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-        self.eng = Engine(board_size=cfg.board_size, history_len=cfg.history_len, games=self.G, komi=cfg.komi,
-                          num_simulations=cfg.mcts_simulations, c_base=cfg.c_base, c_init=cfg.c_init,
-                          dirichlet_alpha=cfg.dirichlet_alpha, dirichlet_eps=cfg.dirichlet_eps,
-                          inference_batch_size=cfg.mcts_inference_batch, topk_expand=cfg.mcts_topk_expand,
-                          virtual_loss=cfg.mcts_virtual_loss, dedup_leaves=dedup_leaves, device=self.dev)
-        if hasattr(model, "native"):
-            self.net = model.native(precision, self.dev)
-            self.layout = self.net.layout
-            self.eval = self.net.forward
-        else:  # plain callable on device tensors: feats f32 NCHW -> (logits, values)
-            self.net, self.layout, self.eval = None, N.AZ_FEAT_F32_NCHW, model
-        self.rng = HostRng(self.G, rng_threads)
-        self.A = self.eng.A
-        self.max_rows = self.eng.max_rows
-        if self.layout == N.AZ_FEAT_BF16_NHWC:
-            self.feat_buf = torch.empty((self.max_rows, cfg.board_size ** 2, self.eng.cpad), dtype=torch.bfloat16, device=self.dev)
-        else:
-            self.feat_buf = torch.empty((self.max_rows, self.eng.Cp, cfg.board_size, cfg.board_size), dtype=torch.float32, device=self.dev)
+        lanes = max(1, min(int(lanes), self.G))
         self.counters = dict(moves=0, sims=0, nn_rows=0, nn_rows_nodedup=0, games=0, steps=0, depth_sum=0,
                              t_host_rng=0.0, t_host_policy=0.0, t_samples=0.0)
+        share = [self.G // lanes + (1 if i < self.G % lanes else 0) for i in range(lanes)]
+        self.lanes = [_Lane(self, i, g, model, precision, dedup_leaves, rng_threads, own_stream=lanes > 1)
+                      for i, g in enumerate(share)]
+        if tower_workgroups is not None:
+            for ln in self.lanes:
+                if ln.net is not None and precision == "bf16":
+                    ln.net.set_tower_workgroups(tower_workgroups)
+        self.A = self.lanes[0].A
+        self.num_games, self.next_id = 0, 0
+        self.finished, self.results = {}, [0, 0, 0]
 
-    # ------------------------------------------------------------------ one lockstep search
-    def _search(self, enable: np.ndarray):
-        eng, c = self.eng, self.counters
-        eng.search_begin(torch.from_numpy(enable.astype(np.uint8)))
-        rows = eng.pending()
-        if rows == 0:
-            return None, None
-        feats = eng.gather(rows, self.layout, out=self.feat_buf)
-        logits, values = self.eval(feats[:rows])
-        counts = eng.root_legal_counts().cpu().numpy()
-        t0 = time.perf_counter()
-        noise = self.rng.dirichlet(counts, self.cfg.dirichlet_alpha, self.A)
-        c["t_host_rng"] += time.perf_counter() - t0
-        done = eng.expand(logits, values, torch.from_numpy(noise))
-        c["nn_rows"] += rows
-        c["nn_rows_nodedup"] += rows
-        while not done:
-            eng.search_select()
-            rows = eng.pending()
-            if rows > 0:
-                feats = eng.gather(rows, self.layout, out=self.feat_buf)
-                logits, values = self.eval(feats[:rows])
-                done = eng.expand(logits, values)
-                c["nn_rows"] += rows
-            else:
-                done = eng.expand(None, None)
-        st = eng.stats()
-        c["sims"] += st["sims"]
-        c["nn_rows_nodedup"] += st["rows_raw"]
-        c["depth_sum"] += st["depth_sum"]
-        visits, rv = eng.result()
-        return visits.cpu().numpy(), rv.cpu().numpy()
+    # single-lane conveniences
+    eng = property(lambda self: self.lanes[0].eng)
+    net = property(lambda self: self.lanes[0].net)
+    log = property(lambda self: self.lanes[0].log)
+    async_search = property(lambda self: all(ln.async_search for ln in self.lanes))
+
+    def set_async(self, enable: bool):
+        """Switch between enqueueing the batches of a search without host round trips and one round trip per batch."""
+        for ln in self.lanes:
+            ok = bool(enable) and ln.net is not None and ln.layout == N.AZ_FEAT_BF16_NHWC
+            ln.async_search = ok
+            ln.eng.set_async(ok)
+
+    def _deal(self) -> int:
+        if self.next_id >= self.num_games:
+            return -1
+        self.next_id += 1
+        return self.next_id - 1
 
     # ------------------------------------------------------------------ driver
     def begin(self, num_games: int | None = None):
         """Reset every slot to a new game; game ids 0..num_games-1 are dealt to slots as they free up."""
-        G = self.G
-        self.num_games = G if num_games is None else int(num_games)
-        self.game_id = np.full(G, -1, np.int64)
-        self.move_idx = np.zeros(G, np.int64)
+        self.num_games = self.G if num_games is None else int(num_games)
         self.next_id = 0
-        self.eng.reset()
-        for s in range(G):
-            if self.next_id < self.num_games:
-                self.game_id[s] = self.next_id
-                self.rng.seed(s, self.seed0 + self.next_id)
-                self.next_id += 1
-        self.traj = [[] for _ in range(G)]   # per slot: (packed planes, capf, pi f32, to_play, difficulty)
-        self.finished = {}                   # game id -> (trajectory, winner)
+        self.finished = {}                   # game id -> (lane, slot, first step, last step + 1, winner)
         self.results = [0, 0, 0]             # black wins, white wins, draws
+        for ln in self.lanes:
+            ln.begin()
 
     def busy(self) -> bool:
-        return bool((self.game_id >= 0).any())
+        return any(ln.busy() for ln in self.lanes)
 
     def step(self):
         """One lockstep move of every running game (one selfplay_game loop iteration each, train.py:322-343)."""
-        cfg, G, eng, c = self.cfg, self.G, self.eng, self.counters
-        A, H, n = self.A, cfg.history_len, cfg.board_size
-        game_id, move_idx = self.game_id, self.move_idx
-        active = game_id >= 0
-        _, info = eng.status()
-        to_play = info.cpu().numpy()[:, 0].copy()
-        planes = eng.features(N.AZ_FEAT_F32_NCHW) if self.collect else None
-        visits, rv = self._search(active)
-        t0 = time.perf_counter()
-        temps = np.where(move_idx < cfg.temp_moves, cfg.temp_start,
-                         np.where(move_idx < cfg.temp_mid_moves, cfg.temp_mid, cfg.temp_end)).astype(np.float64)
-        act_rows = np.nonzero(active)[0]
-        pi = np.zeros((G, A), np.float64)
-        pi[act_rows] = policy_from_visits(visits[act_rows].astype(np.float64), temps[act_rows])
-        u = self.rng.random_sample(active)
-        actions = np.full(G, -1, np.int32)
-        actions[act_rows] = sample_actions(pi[act_rows], u[act_rows])
-        pi32 = pi.astype(np.float32)
-        c["t_host_policy"] += time.perf_counter() - t0
-        t0 = time.perf_counter()
-        if self.collect:
-            pl = planes.cpu().numpy()
-            bits = np.packbits(pl[:, : 2 * H + 3].reshape(G, -1) > 0.5, axis=1)
-            caps = pl[:, 2 * H + 3:, 0, 0].copy()
-            diff = np.maximum(0.01, 1.0 - pi32.max(axis=1).astype(np.float64))      # train.py:336-337
-            for s in act_rows:
-                self.traj[s].append((bits[s], caps[s], pi32[s].copy(), int(to_play[s]), float(diff[s])))
-        c["t_samples"] += time.perf_counter() - t0
-        # resignation (train.py:339-341) ends the game before the move is played
-        resigned = np.zeros(G, np.int64)
-        if not cfg.disable_resign:
-            rs = active & (np.abs(rv) >= cfg.resign_threshold) & (move_idx >= 12)
-            resigned[rs] = np.where(rv[rs] < 0, -to_play[rs], to_play[rs])
-        actions[resigned != 0] = -1
-        eng.play(torch.from_numpy(actions))
-        move_idx[active & (resigned == 0)] += 1
-        c["moves"] += int(active.sum())
-        _, info = eng.status()
-        info = info.cpu().numpy()
-        over = active & ((info[:, 6] != 0) | (resigned != 0))
-        if over.any():
-            reset = np.zeros(G, np.uint8)
-            for s in np.nonzero(over)[0]:
-                winner = int(resigned[s]) if resigned[s] != 0 else int(info[s, 7])
-                self.results[0 if winner == 1 else (1 if winner == -1 else 2)] += 1
-                self.finished[int(game_id[s])] = (self.traj[s], winner)
-                self.traj[s] = []
-                c["games"] += 1
-                move_idx[s] = 0
-                if self.next_id < self.num_games:
-                    game_id[s] = self.next_id
-                    self.rng.seed(s, self.seed0 + self.next_id)
-                    self.next_id += 1
-                    reset[s] = 1
-                else:
-                    game_id[s] = -1
-            if reset.any():
-                eng.reset(torch.from_numpy(reset))
-        c["steps"] += 1
+        if len(self.lanes) == 1:
+            self.lanes[0].launch()
+            self.lanes[0].finish()
+        else:
+            for ln in self.lanes:
+                ln.finish()
+                ln.launch()
+        self.counters["steps"] += 1
+
+    def flush(self):
+        for ln in self.lanes:
+            ln.finish()
 
     def run(self, num_games: int | None = None, max_steps: int | None = None):
         """Play `num_games` games (default: one per slot), or stop after `max_steps` lockstep moves."""
@@ -256,19 +374,64 @@ class BatchedSelfPlay:
         while self.busy() and (max_steps is None or steps < max_steps):
             self.step()
             steps += 1
+        self.flush()
         return self.collect_samples()
 
+    def profile(self, enable: bool, read: bool = False):
+        """Tower-kernel timing over all lanes. read=True returns (sum of launch ms, launches, merged busy ms):
+        the last is the length of the union of the launch intervals, i.e. launches that overlap on different
+        streams are not counted twice."""
+        nets = [ln.net for ln in self.lanes if ln.net is not None and ln.layout == N.AZ_FEAT_BF16_NHWC]
+        out = None
+        if read:
+            spans = [n.profile_spans() for n in nets]
+            spans = np.concatenate(spans) if spans else np.zeros((0, 2))
+            total, launches = 0.0, 0
+            for n in nets:
+                ms, ln_, _ = n.profile(enable, read=True)
+                total += ms
+                launches += ln_
+            busy, end = 0.0, -np.inf
+            for a, b in spans[np.argsort(spans[:, 0])]:
+                if b > end:
+                    busy += b - max(a, end)
+                    end = b
+            out = (total, launches, busy)
+        else:
+            for n in nets:
+                n.profile(enable)
+        return out
+
+    def trajectory(self, gid: int):
+        """(list of (packed planes, capf, pi f32, to_play, difficulty) per move, winner) of a finished game."""
+        lane, slot, a, b, winner = self.finished[gid]
+        ln = self.lanes[lane]
+        out = []
+        for k in range(a - ln.log_base, b - ln.log_base):
+            bits, caps, pi32, to_play, diff = ln.log[k]
+            out.append((bits[slot], caps[slot], pi32[slot], int(to_play[slot]), float(diff[slot])))
+        return out, winner
+
     def collect_samples(self):
+        """Samples of the games finished so far, in game-id order (train.py:346-353)."""
         n, H = self.cfg.board_size, self.cfg.history_len
         nbin = (2 * H + 3) * n * n
         samples = []
         for gid in sorted(self.finished):
-            tr, winner = self.finished[gid]
+            tr, winner = self.trajectory(gid)
             for packed, capf, p, player, difficulty in tr:
-                z = 0.0 if winner == 0 else (1.0 if winner == player else -1.0)      # train.py:346-353
+                z = 0.0 if winner == 0 else (1.0 if winner == player else -1.0)
                 samples.append((self._unpack(packed, capf, nbin), p, z, max(difficulty, abs(z) * 0.25)))
         bw, ww, dd = self.results
         return samples, int(bw), int(ww), int(dd)
+
+    def drain_samples(self):
+        """collect_samples(), then forget the finished games and the log entries no running game needs."""
+        out = self.collect_samples()
+        self.finished.clear()
+        for ln in self.lanes:
+            ln.prune_log()
+        return out
 
     def _unpack(self, packed, capf, nbin):
         n, H = self.cfg.board_size, self.cfg.history_len

@@ -95,6 +95,8 @@ def main():
     ap.add_argument("--games", type=int, default=4096, help="lockstep games per GPU")
     ap.add_argument("--batch", type=int, default=16, help="mcts inference batch (README value 16; upstream default 8)")
     ap.add_argument("--no-dedup", action="store_true", help="evaluate repeated leaves of a batch again, as upstream does")
+    ap.add_argument("--lanes", type=int, default=2, help="independent game lanes (engine + stream each) whose kernels and host work overlap")
+    ap.add_argument("--tower-workgroups", type=int, default=0, help="workgroup limit per tower launch (0: one per CU with 1 lane, 1024 otherwise)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-moves", type=int, default=8)
     a = ap.parse_args()
@@ -117,7 +119,9 @@ def main():
     torch.manual_seed(0)
     net = AlphaZeroNet(channels=CH, num_blocks=BLOCKS).eval().to(torch.device("cuda", local))
     cfg = SelfPlayConfig(mcts_simulations=SIMS, mcts_inference_batch=a.batch, mcts_topk_expand=TOPK, mcts_virtual_loss=VLOSS)
-    sp = BatchedSelfPlay(net, cfg, games=a.games, seed0=1 + rank * a.games, dedup_leaves=not a.no_dedup)
+    twg = a.tower_workgroups if a.tower_workgroups > 0 else (None if a.lanes == 1 else 1024)
+    sp = BatchedSelfPlay(net, cfg, games=a.games, seed0=1 + rank * a.games, dedup_leaves=not a.no_dedup, lanes=a.lanes,
+                         tower_workgroups=twg)
     sp.begin(num_games=10 ** 9)          # slots refill for as long as the run lasts
     for _ in range(a.warmup):
         sp.step()
@@ -129,14 +133,14 @@ def main():
 
     for k in sp.counters:
         sp.counters[k] = 0
-    sp.net.profile(True)
+    sp.profile(True)
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         sp.step()
     barrier()
     dt = time.perf_counter() - t0
-    tower_ms, launches, tower_rows = sp.net.profile(False, read=True)
+    tower_ms_sum, launches, tower_ms = sp.profile(False, read=True)   # tower_ms: merged (overlap counted once)
 
     c = sp.counters
     mine = torch.tensor([dt, c["sims"], c["nn_rows"], c["nn_rows_nodedup"], c["moves"], c["games"], c["depth_sum"]],
@@ -157,6 +161,7 @@ def main():
     sims, rows, rows_raw, moves, games, depth_sum = tot[1:]
     fl_pos = tower_flops_per_position()
     per_launch_ms = tower_ms / max(1, launches)
+    tower_rows = c["nn_rows"]      # this rank's rows: every network row of the window went through a timed tower launch
     achieved = (tower_rows * fl_pos) / (tower_ms * 1e-3) / 1e12 if tower_ms > 0 else 0.0
     out = {
         "metric": "MCTS sims/sec (node) + self-play games/hour, 9x9 192ch×12blk @256 sims, 1/2/4/8 GPU",
@@ -165,7 +170,7 @@ def main():
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic (random-init weights, games from the empty board)",
         "config": {"workload": "9x9 full net 192ch x 12 SE blocks, 256 sims/move, top-k 48, virtual loss 1.0, "
                                f"{a.games} lockstep games per GPU (BASELINE.json configs[2])",
-                   "games_per_gpu": a.games, "inference_batch": a.batch, "dedup_repeated_leaves": not a.no_dedup,
+                   "games_per_gpu": a.games, "lanes": a.lanes, "inference_batch": a.batch, "dedup_repeated_leaves": not a.no_dedup,
                    "parallelism": f"games sharded over {world} GPU(s), no data-path collective"},
         "sims_per_s": round(sims / dt_max, 1),
         "nn_rows_per_s": round(rows / dt_max, 1),
@@ -178,6 +183,10 @@ def main():
         "roofline": {"bound": "mfma", "kernel": "k_tower<192,4,2,128>", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS,
                      "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
                      "launches": int(launches), "avg_launch_ms": round(per_launch_ms, 4),
+                     "avg_launch_ms_start_to_end": round(tower_ms_sum / max(1, launches), 4),
+                     "timing": "HIP events around every tower launch on its stream; launches of different lanes overlap, so "
+                               "achieved = FLOPs of all launches / length of the union of their intervals and avg_launch_ms = "
+                               "that length / launches; avg_launch_ms_start_to_end is the plain mean of (end - start)",
                      "rows_per_launch": round(tower_rows / max(1, launches), 1), "flop_per_position": fl_pos,
                      "tower_share_of_wall": round(tower_ms * 1e-3 / dt, 4)},
         "host_seconds": {"rng": round(c["t_host_rng"], 4), "policy": round(c["t_host_policy"], 4), "samples": round(c["t_samples"], 4)},

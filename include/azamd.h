@@ -103,6 +103,14 @@ int az_mcts_select(az_engine* e, void* stream);
 /* Number of pending rows. Synchronises `stream`. Also reports and clears per-game failures
  * (returns AZ_ERR_NOCHILD / AZ_ERR_CAPACITY). */
 int az_mcts_pending(az_engine* e, int32_t* rows_out, void* stream);
+/* Asynchronous mode (enable != 0): az_mcts_gather and az_mcts_expand never synchronise; launches are
+ * sized by upper bounds (G rows for the roots, az_engine_max_rows for a batch) and surplus workers
+ * exit on the device-side row count, so a whole search can be enqueued without host round trips.
+ * Failures are then reported by the next az_mcts_pending / az_mcts_stats call. */
+int az_mcts_set_async(az_engine* e, int32_t enable);
+/* Device address of the int32 pending-row count (valid on `stream` after az_mcts_begin/az_mcts_select),
+ * for consumers that size their work on the device (az_net_forward_indirect). */
+int az_mcts_rows_device(az_engine* e, const int32_t** rows_dev_out);
 /* Leaf gather: feature planes of the pending rows, dense, in row order (mcts.py:61). */
 int az_mcts_gather(az_engine* e, void* feat_out_dev, int32_t layout, void* stream);
 /* Row bookkeeping for callers that want it: game index int32 [rows] of each pending row. */
@@ -145,12 +153,23 @@ int az_net_load(az_net* net, const float* params_host, int64_t count);
 int az_net_forward(az_net* net, const void* feat_dev, int32_t rows, float* logits_dev, float* values_dev,
                    void* stream);
 
+/* Same with the row count read on the device from *rows_dev (<= max_rows): no host round trip. */
+int az_net_forward_indirect(az_net* net, const void* feat_dev, const int32_t* rows_dev, int32_t max_rows,
+                            float* logits_dev, float* values_dev, void* stream);
 /* Timing of the dominant kernel (the fused tower) with HIP events recorded on the launch stream.
  * If the three output pointers are non-NULL they receive the total milliseconds, launch count and
  * row count accumulated since profiling was last enabled (synchronises on the recorded events);
  * then profiling is switched on (enable != 0) or off with the counters cleared. bf16 path only.
  * No upstream counterpart: measurement aid for bench.py. */
 int az_net_profile(az_net* net, int32_t enable, double* tower_ms, int64_t* launches, int64_t* rows);
+/* [start, end] in ms of each timed launch since profiling was enabled (before az_net_profile reads and
+ * clears them), on one time line per device that all networks and streams share, so that launches
+ * overlapping on different streams can be merged. Writes min(count, capacity) pairs. */
+int az_net_profile_spans(az_net* net, double* spans_ms, int64_t capacity, int64_t* count);
+/* Upper limit of workgroups per launch of the fused residual-tower kernel (default: one per compute unit,
+ * each looping over its share of the boards). A larger limit gives shorter-lived workgroups, which lets
+ * launches on other streams interleave at board-group granularity. Synchronises the device. */
+int az_net_set_tower_workgroups(az_net* net, int32_t workgroups);
 
 /* ---- host-side random streams (no device work) ------------------------------------------------ */
 /* One legacy-NumPy-compatible MT19937 stream per game. The upstream code draws from the global

@@ -103,7 +103,7 @@ def test_lockstep_selfplay_reproduces_upstream_game(name, slots):
     sp = BatchedSelfPlay(stub_evaluator(kind), cfg, games=slots, seed0=321)
     samples, bw, ww, dd = sp.run(num_games=slots)
     assert bw + ww + dd == slots
-    traj, winner = sp.finished[0]
+    traj, winner = sp.trajectory(0)
     assert winner == int(z[f"{name}/winner"][0])
     assert len(traj) == len(z[f"{name}/pi"])
     want_actions = z[f"{name}/actions"]
@@ -116,3 +116,56 @@ def test_lockstep_selfplay_reproduces_upstream_game(name, slots):
     assert np.array_equal(np.array([s[3] for s in got]), z[f"{name}/difficulty"])
     assert got[0][0].shape == (21, 5, 5) and got[0][0].dtype == np.float32
     del want_actions
+
+
+def _small_selfplay(lanes, use_async, games=6, num_games=9, steps=None):
+    import torch
+    from alphazero_amd.model import AlphaZeroNet
+    from alphazero_amd.selfplay import BatchedSelfPlay, SelfPlayConfig
+    torch.manual_seed(3)
+    net = AlphaZeroNet(board_size=5, channels=32, num_blocks=2).eval().cuda()
+    cfg = SelfPlayConfig(board_size=5, mcts_simulations=24, mcts_inference_batch=4, mcts_topk_expand=6)
+    sp = BatchedSelfPlay(net, cfg, games=games, seed0=11, lanes=lanes, tower_workgroups=None if lanes == 1 else 1024)
+    assert sp.async_search
+    sp.set_async(use_async)
+    assert sp.async_search == use_async
+    if steps is None:
+        sp.run(num_games=num_games)
+    else:
+        sp.begin(num_games=num_games)
+        for _ in range(steps):
+            sp.step()
+        sp.flush()
+    return sp
+
+
+def test_async_search_equals_synchronous_search():
+    """The lockstep driver enqueues the batches of a search without host round trips when the network is
+    the native bf16 one; the games must be the same as with a round trip per batch."""
+    a = _small_selfplay(1, True, steps=5)
+    b = _small_selfplay(1, False, steps=5)
+    assert len(a.log) == len(b.log) == 5
+    for ra, rb in zip(a.log, b.log):
+        for xa, xb in zip(ra, rb):
+            assert np.array_equal(xa, xb)
+    for k in ("sims", "nn_rows", "nn_rows_nodedup", "depth_sum", "moves"):
+        assert a.counters[k] == b.counters[k], k
+
+
+@pytest.mark.parametrize("lanes", [2, 3])
+def test_pipelined_lanes_play_the_same_games(lanes):
+    """Games depend on their id only: splitting the slots over lanes that run on their own streams, with
+    the moves of one lane overlapping the searches of the others, must not change any trajectory."""
+    one = _small_selfplay(1, True)
+    many = _small_selfplay(lanes, True)
+    assert sorted(one.finished) == sorted(many.finished) == list(range(9))
+    assert one.results == many.results
+    for gid in range(9):
+        ta, wa = one.trajectory(gid)
+        tb, wb = many.trajectory(gid)
+        assert wa == wb and len(ta) == len(tb)
+        for ma, mb in zip(ta, tb):
+            for xa, xb in zip(ma, mb):
+                assert np.array_equal(xa, xb)
+    sa, sb = one.collect_samples(), many.collect_samples()
+    assert len(sa[0]) == len(sb[0]) and sa[1:] == sb[1:]
