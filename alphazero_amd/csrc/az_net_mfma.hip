@@ -5,10 +5,12 @@
 // on 9x9); their activations stay in LDS ([position][channel] bf16) from the first layer to the last
 // and the residual stream stays in registers, so the only HBM/L2 traffic of the tower is the weight
 // stream. Each 3x3 convolution is an implicit GEMM: M = 256 positions, N = C output channels,
-// K = 9*C, computed with v_mfma_f32_32x32x16_bf16 by 8 waves (each wave a 64 x C/2 or 32 x C tile).
-// Board edges are handled by pointing out-of-board taps at a zero row in LDS. Weights are packed at
-// load time into the exact LDS image the B fragments are read from, tile after tile, and streamed
-// global -> LDS (global_load_lds, no staging registers) one K-tile ahead of the MFMAs.
+// K = 9*C, computed with v_mfma_f32_16x16x32_bf16 by 8 waves (each wave 64 positions x C/2 channels, or
+// 32 x C). The weights are the MFMA's row operand, so a lane ends up with consecutive output channels
+// of one position and writes them back with 16-byte LDS stores. Board edges are handled by pointing
+// out-of-board taps at a zero row in LDS. Weights are packed at load time into the exact LDS image the
+// fragments are read from, tile after tile, and streamed global -> LDS (global_load_lds, no staging
+// registers) ahead of the MFMAs.
 // The SE pooling adds a board's positions in index order (one thread per board and channel), so the
 // output of a position does not depend on which other boards share its workgroup or launch.
 //
@@ -31,7 +33,7 @@ int fail(int code, const std::string& msg);
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 struct TowerParams {
     int n, np, TB, rows, blocks, use_se, hid, cin_pad, q;
@@ -98,138 +100,341 @@ __device__ __forceinline__ void stage_tile(const uint4* __restrict__ src, char* 
 // Per-lane coordinates inside the workgroup tile. Every phase of the kernel re-derives them from an
 // opaque copy of threadIdx.x, so nothing computed from them is hoisted across the big layer loop
 // (the optimiser otherwise precomputes hundreds of addresses there and spills them).
-#define AZ_LANE_GEO(NI_)                                                                          \
+// A wave owns 16*MI positions (rows of the activation image) and 16*NI output channels. In every
+// 16x16 MFMA tile the lane holds position lr and the four channels 4*kq..4*kq+3 of the tile; tiles
+// 2p and 2p+1 are packed so that together they give the lane 8 consecutive channels (see pack_conv).
+#define AZ_LANE_GEO(MI_, NI_, WN_)                                                                \
     const int t_ = opaque((int)threadIdx.x);                                                      \
-    const int lane = t_ & 63, wave = t_ >> 6, wm = wave / WN, wn = wave - wm * WN;                \
-    const int h = lane >> 5, l31 = lane & 31;                                                     \
-    const int row_base = wm * (32 * MI), col0 = wn * ((NI_) * 32);                                \
-    (void)row_base; (void)col0; (void)h; (void)l31; (void)wave
+    const int lane = t_ & 63, wave = t_ >> 6, wm = wave / (WN_), wn = wave - wm * (WN_);          \
+    const int lr = lane & 15, kq = lane >> 4;                                                     \
+    const int row_base = wm * (16 * (MI_)), col0 = wn * ((NI_) * 16);                             \
+    (void)row_base; (void)col0; (void)lr; (void)kq; (void)wave
 
 struct TileGeo {   // wave-uniform facts about the workgroup's tile
     int n, np, vrows;
     unsigned recip_np, recip_n;
 };
 
-// Implicit-GEMM over `ntiles` K-tiles of KT channels each (tiles_per_tap tiles per 3x3 tap).
-// acc[mi][ni] += A(positions x K) * B(K x columns). A rows come from `act` (row stride in_stride
-// bytes, zero row at zrow); B tiles are streamed from `wg` through the two LDS buffers at bbuf,
-// tile t+1 in flight while tile t feeds the MFMAs.
-template <int MI, int NI, int KT, int WM, int WN>
-__device__ __forceinline__ void gemm_taps(f32x16 (&acc)[MI][NI], const uint4* __restrict__ wg, int ntiles, int tiles_per_tap,
-                                          int N, bool three, const char* act, int in_stride, const char* zrow, char* bbuf,
-                                          const TileGeo& g) {
-    constexpr int NW = WM * WN;
-    AZ_LANE_GEO(NI);
-    const int tile_bytes = KT * N * 2;
-    const int nvec = tile_bytes / 16;
-    stage_tile<NW>(wg, bbuf, nvec, lane, wave);
-    // row geometry of this lane's A fragments
-    int ry[MI], rx[MI], roff[MI];
-    bool rvalid[MI];
+// LDS byte offsets (from `act`) of the lane's activation fragments for k-step (tap, cc): position
+// row + tap shift, 8 channels at 32*cc + 8*kq. Taps that leave the board, rows past the valid ones and
+// padding k-steps (tap >= ntaps) read the zero row.
+template <int MI>
+__device__ __forceinline__ void frag_offsets(int (&out)[MI], const int (&ry)[MI], const int (&rx)[MI], const int (&roff)[MI], int tap, int cc,
+                                             int ntaps, bool three, int n, int in_stride, int zoff) {
+    const int dy = three ? tap / 3 - 1 : 0, dx = three ? tap - (tap / 3) * 3 - 1 : 0;
+    const int shift = (dy * n + dx) * in_stride + cc * 64;
+    const bool tap_ok = tap < ntaps;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
-        const int row = row_base + mi * 32 + l31;
+        const int yy = ry[mi] + dy, xx = rx[mi] + dx;
+        const bool ok = tap_ok & ((unsigned)yy < (unsigned)n) & ((unsigned)xx < (unsigned)n);
+        out[mi] = (ok ? roff[mi] + shift : zoff + cc * 64);
+    }
+}
+
+// Implicit GEMM acc[mi][ni] += W(16 channels x K) * X(K x 16 positions) over `nksteps` (even) k-steps of
+// 32 input channels, `kpt` k-steps per 3x3 tap. Weight tiles (two k-steps each) are streamed from `wg`
+// through the two LDS buffers at bbuf. The workgroup barrier of a tile sits between its two k-steps:
+// by then every wave holds the tile's last fragments in registers, so the buffer can be refilled (two
+// tiles ahead) and the MFMAs of the second k-step run while the first fragments of the next tile are
+// fetched -- the matrix pipe never waits for LDS at a tile boundary.
+template <int MI, int NI, int WM, int WN, int NCOLS, bool SAME_TAP>
+__device__ __forceinline__ void gemm_taps(f32x4 (&acc)[MI][NI], const uint4* __restrict__ wg, int nksteps, int kpt, int ntaps, bool three,
+                                          const char* act, int in_stride, const char* zrow, char* bbuf, const TileGeo& g) {
+    constexpr int NW = WM * WN;
+    constexpr int N = NCOLS;
+    constexpr int tile_bytes = 64 * N * 2, nvec = tile_bytes / 16, kstep_bytes = tile_bytes / 2;
+    constexpr int NCHUNK = nvec / 64;                 // 1 KiB pieces per weight tile
+    constexpr int PW = (NCHUNK + NW - 1) / NW;        // pieces per wave
+    AZ_LANE_GEO(MI, NI, WN);
+    const int ntiles = nksteps >> 1;
+    stage_tile<NW>(wg, bbuf, nvec, lane, wave);
+    if (ntiles > 1) stage_tile<NW>(wg + nvec, bbuf + tile_bytes, nvec, lane, wave);
+    // Tiles 2.. go through registers: fetched two tiles ahead, written to LDS one tile ahead.
+    constexpr bool RAGGED = (NCHUNK % NW) != 0;       // the last piece round does not cover every wave
+    uint4 stg[PW];
+    const uint4* wsrc = wg + lane + wave * 64;        // this lane's vector of piece `wave` of tile 0
+#pragma unroll
+    for (int i = 0; i < PW; ++i) {
+        stg[i] = make_uint4(0, 0, 0, 0);
+        if (ntiles > 2 && (!RAGGED || wave + i * NW < NCHUNK)) stg[i] = wsrc[(size_t)2 * nvec + i * NW * 64];
+    }
+    int ry[MI], rx[MI], roff[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int row = row_base + mi * 16 + lr;
         const int b = (row * g.recip_np) >> 16, p = row - b * g.np;
         ry[mi] = (p * g.recip_n) >> 16;
         rx[mi] = p - ry[mi] * g.n;
-        roff[mi] = row * in_stride;
-        rvalid[mi] = row < g.vrows;
+        if (row >= g.vrows) ry[mi] = -64;   // fails every bounds check
+        roff[mi] = row * in_stride + kq * 16;
     }
-    const int zoff = (int)(zrow - act);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int zoff = (int)(zrow - act) + kq * 16;
+    const int woff = ((wn * NI) * 64 + lane) * 16;   // this wave's first channel tile inside a k-step image
+    const int soff = (wave * 64 + lane) * 16;        // where this lane's staged vector of piece `wave` goes
+    int tap = 0, cc = 0;   // cursor: the next k-step whose offsets are to be computed
+    int ap0[MI], ap1[MI];
+    frag_offsets<MI>(ap0, ry, rx, roff, tap, cc, ntaps, three, g.n, in_stride, zoff);
+    if (SAME_TAP) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) ap1[mi] = ap0[mi] + 64;
+        cc += 2;
+    } else {
+        if (++cc == kpt) { cc = 0; ++tap; }
+        frag_offsets<MI>(ap1, ry, rx, roff, tap, cc, ntaps, three, g.n, in_stride, zoff);
+        ++cc;
+    }
+    if (cc >= kpt) { cc = 0; ++tap; }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");   // tiles 0 and 1 have landed; the register fetch may still fly
     __syncthreads();
-    for (int t = 0; t < ntiles; ++t) {
-        const char* cur = bbuf + (t & 1) * tile_bytes;
-#ifdef AZ_DIAG_SAMETILE
-        if (t + 1 < ntiles) stage_tile<NW>(wg, bbuf + ((t + 1) & 1) * tile_bytes, nvec, lane, wave);
-        else
-#endif
-        if (t + 1 < ntiles) stage_tile<NW>(wg + (size_t)(t + 1) * nvec, bbuf + ((t + 1) & 1) * tile_bytes, nvec, lane, wave);
-        const int tap = t / tiles_per_tap, c0 = (t - tap * tiles_per_tap) * KT;
-        const int dy = three ? tap / 3 - 1 : 0, dx = three ? tap - (tap / 3) * 3 - 1 : 0;
-        const char* ap[MI];
+    bf16x8 a0[MI], b0[NI], a1[MI], b1[NI];
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-            const int yy = ry[mi] + dy, xx = rx[mi] + dx;
-            const bool ok = rvalid[mi] & ((unsigned)yy < (unsigned)g.n) & ((unsigned)xx < (unsigned)g.n);
-            const int off = ok ? roff[mi] + (dy * g.n + dx) * in_stride : zoff;
-            ap[mi] = act + off + c0 * 2 + h * 16;
+    for (int mi = 0; mi < MI; ++mi) a0[mi] = *(const bf16x8*)(act + ap0[mi]);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) b0[ni] = *(const bf16x8*)(bbuf + woff + ni * 1024);
+    for (int t = 0; t + 1 < ntiles; ++t) {
+        char* X = bbuf + (t & 1) * tile_bytes;
+        const char* Y = bbuf + ((t + 1) & 1) * tile_bytes;
+        // ---- first k-step: fetch the second k-step's fragments meanwhile
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) a1[mi] = *(const bf16x8*)(act + ap1[mi]);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) b1[ni] = *(const bf16x8*)(X + kstep_bytes + woff + ni * 1024);
+        frag_offsets<MI>(ap0, ry, rx, roff, tap, cc, ntaps, three, g.n, in_stride, zoff);   // next tile
+        if (SAME_TAP) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) ap1[mi] = ap0[mi] + 64;
+            cc += 2;
+        } else {
+            if (++cc == kpt) { cc = 0; ++tap; }
+            frag_offsets<MI>(ap1, ry, rx, roff, tap, cc, ntaps, three, g.n, in_stride, zoff);
+            ++cc;
         }
-        const char* bp = cur + ((size_t)h * N + col0 + l31) * 16;
-        // fragments of k-step ks+1 are fetched from LDS while the MFMAs of k-step ks run
-        constexpr int KS = KT / 16;
-        bf16x8 a[2][MI], b[2][NI];
+        if (cc >= kpt) { cc = 0; ++tap; }
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) a[0][mi] = *(const bf16x8*)(ap[mi]);
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) b[0][ni] = *(const bf16x8*)(bp + (size_t)(ni * 32) * 16);
+            for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[ni], a0[mi], acc[mi][ni], 0, 0, 0);
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            if (ks + 1 < KS) {
+        for (int i = 0; i < MI * NI; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (i < MI + NI) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        // ---- tile boundary: X is free once every wave has its fragments; tile t+1 is complete in Y
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 2 < ntiles) {   // tile t+2 (fetched a tile ago) -> X; start fetching tile t+3
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi) a[(ks + 1) & 1][mi] = *(const bf16x8*)(ap[mi] + (ks + 1) * 32);
+            for (int i = 0; i < PW; ++i)
+                if (!RAGGED || wave + i * NW < NCHUNK) *(uint4*)(X + soff + i * NW * 1024) = stg[i];
+            if (t + 3 < ntiles) {
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni)
-                    b[(ks + 1) & 1][ni] = *(const bf16x8*)(bp + ((size_t)(ks + 1) * 2 * N + ni * 32) * 16);
+                for (int i = 0; i < PW; ++i)
+                    if (!RAGGED || wave + i * NW < NCHUNK) stg[i] = wsrc[(size_t)(t + 3) * nvec + i * NW * 64];
             }
+        }
+        // ---- second k-step: fetch the first fragments of the next tile meanwhile
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) a0[mi] = *(const bf16x8*)(act + ap0[mi]);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) b0[ni] = *(const bf16x8*)(Y + woff + ni * 1024);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[ni], a1[mi], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < MI * NI; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (i < MI + NI) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+    }
+    {   // last tile
+        const char* X = bbuf + ((ntiles - 1) & 1) * tile_bytes;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) a1[mi] = *(const bf16x8*)(act + ap1[mi]);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) b1[ni] = *(const bf16x8*)(X + kstep_bytes + woff + ni * 1024);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[ni], a0[mi], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < MI * NI; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (i < MI + NI) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[ni], a1[mi], acc[mi][ni], 0, 0, 0);
+    }
+}
+
+// The same GEMM for layers whose taps span an even number KPT of k-steps (every layer with C >= 64): the
+// tile loop is unrolled over the KPT/2 tiles of a tap, so the channel offsets are instruction immediates
+// and the only per-tap vector work is one select per fragment row between the shifted position and the
+// zero row (from a per-lane 9-bit mask of the taps that stay on the board).
+template <int MI, int NI, int WM, int WN, int NCOLS, int KPT>
+__device__ __forceinline__ void gemm_conv(f32x4 (&acc)[MI][NI], const uint4* __restrict__ wg, int ntaps, bool three, const char* act,
+                                          int in_stride, const char* zrow, char* bbuf, const TileGeo& g) {
+    constexpr int NW = WM * WN;
+    constexpr int TPT = KPT / 2;                      // tiles per tap
+    constexpr int tile_bytes = 64 * NCOLS * 2, nvec = tile_bytes / 16, kstep_bytes = tile_bytes / 2;
+    constexpr int NCHUNK = nvec / 64;                 // 1 KiB pieces per weight tile
+    constexpr int PW = (NCHUNK + NW - 1) / NW;        // pieces per wave
+    constexpr bool RAGGED = (NCHUNK % NW) != 0;       // the last piece round does not cover every wave
+    static_assert(KPT % 2 == 0, "taps must cover whole tiles");
+    AZ_LANE_GEO(MI, NI, WN);
+    const int ntiles = ntaps * TPT;
+    stage_tile<NW>(wg, bbuf, nvec, lane, wave);
+    if (ntiles > 1) stage_tile<NW>(wg + nvec, bbuf + tile_bytes, nvec, lane, wave);
+    // Tiles 2.. go through registers: fetched two tiles ahead, written to LDS one tile ahead.
+    uint4 stg[PW];
+    const uint4* wsrc = wg + lane + wave * 64;        // this lane's vector of piece `wave` of tile 0
+#pragma unroll
+    for (int i = 0; i < PW; ++i) {
+        stg[i] = make_uint4(0, 0, 0, 0);
+        if (ntiles > 2 && (!RAGGED || wave + i * NW < NCHUNK)) stg[i] = wsrc[(size_t)2 * nvec + i * NW * 64];
+    }
+    int roff[MI], vmask[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int row = row_base + mi * 16 + lr;
+        const int b = (row * g.recip_np) >> 16, p = row - b * g.np;
+        const int y = (p * g.recip_n) >> 16, x = p - y * g.n;
+        int m = 0;
+        if (row < g.vrows) {
+            if (three) {
+#pragma unroll
+                for (int tp = 0; tp < 9; ++tp) {
+                    const int yy = y + tp / 3 - 1, xx = x + tp % 3 - 1;
+                    if ((unsigned)yy < (unsigned)g.n && (unsigned)xx < (unsigned)g.n) m |= 1 << tp;
+                }
+            } else {
+                m = 1;
+            }
+        }
+        vmask[mi] = m;
+        roff[mi] = row * in_stride + kq * 16;
+    }
+    const int zoff = (int)(zrow - act) + kq * 16;
+    const int woff = ((wn * NI) * 64 + lane) * 16;   // this wave's first channel tile inside a k-step image
+    const int soff = (wave * 64 + lane) * 16;        // where this lane's staged vector of piece `wave` goes
+    int apc[MI], apn[MI];                            // fragment offsets of the current / next tap (channel offset 0)
+    auto tap_offsets = [&](int (&out)[MI], int tap) {
+        const int dy = three ? tap / 3 - 1 : 0, dx = three ? tap - (tap / 3) * 3 - 1 : 0;
+        const int shift = (dy * g.n + dx) * in_stride;
+        const int bit = tap < ntaps ? 1 << tap : 0;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) out[mi] = (vmask[mi] & bit) ? roff[mi] + shift : zoff;
+    };
+    tap_offsets(apc, 0);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");   // tiles 0 and 1 have landed; the register fetch may still fly
+    __syncthreads();
+    bf16x8 a0[MI], b0[NI], a1[MI], b1[NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) a0[mi] = *(const bf16x8*)(act + apc[mi]);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) b0[ni] = *(const bf16x8*)(bbuf + woff + ni * 1024);
+    int t = 0;
+    for (int tap = 0; tap < ntaps; ++tap) {
+        tap_offsets(apn, tap + 1);
+#pragma unroll
+        for (int u = 0; u < TPT; ++u, ++t) {
+            const int par = (t & 1) * tile_bytes;
+            char* X = bbuf + par;
+            const char* Y = bbuf + (tile_bytes - par);
+            const char* xb = X + woff;
+            const char* yb = Y + woff;
+            // ---- first k-step: fetch the second k-step's fragments meanwhile
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) a1[mi] = *(const bf16x8*)(act + apc[mi] + (u * 128 + 64));
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) b1[ni] = *(const bf16x8*)(xb + kstep_bytes + ni * 1024);
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks & 1][mi], b[ks & 1][ni], acc[mi][ni], 0, 0, 0);
-        }
-        // pin the software pipeline: the LDS reads of k-step ks+1 are issued between the MFMAs of k-step ks
-        __builtin_amdgcn_sched_group_barrier(0x100, MI + NI, 0);
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
+                for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[ni], a0[mi], acc[mi][ni], 0, 0, 0);
 #pragma unroll
             for (int i = 0; i < MI * NI; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if (ks + 1 < KS && i < MI + NI) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                if (i < MI + NI) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next tile has landed in LDS
-        __syncthreads();
+            // ---- tile boundary: X is free once every wave has its fragments; tile t+1 is complete in Y
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 2 < ntiles) {   // tile t+2 (fetched a tile ago) -> X; start fetching tile t+3
+#pragma unroll
+                for (int i = 0; i < PW; ++i)
+                    if (!RAGGED || wave + i * NW < NCHUNK) *(uint4*)(X + soff + i * NW * 1024) = stg[i];
+                if (t + 3 < ntiles) {
+#pragma unroll
+                    for (int i = 0; i < PW; ++i)
+                        if (!RAGGED || wave + i * NW < NCHUNK) stg[i] = wsrc[(size_t)(t + 3) * nvec + i * NW * 64];
+                }
+            }
+            // ---- second k-step: fetch the first fragments of the next tile meanwhile (after the last tile: of
+            // the zero row and a stale buffer, never used)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+                a0[mi] = u + 1 < TPT ? *(const bf16x8*)(act + apc[mi] + (u + 1) * 128) : *(const bf16x8*)(act + apn[mi]);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) b0[ni] = *(const bf16x8*)(yb + ni * 1024);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[ni], a1[mi], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < MI * NI; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (i < MI + NI) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+        }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) apc[mi] = apn[mi];
     }
 }
 
 template <int MI, int NI>
-__device__ __forceinline__ void zero_acc(f32x16 (&acc)[MI][NI]) {
+__device__ __forceinline__ void zero_acc(f32x4 (&acc)[MI][NI]) {
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+            for (int r = 0; r < 4; ++r) acc[mi][ni][r] = 0.f;
 }
 
-// act <- bf16(f(acc + bias)) with f = relu or identity; optionally park the packed values in xres
-// (the residual stream: each thread's private slice, L2-resident traffic).
+// act <- bf16(f(acc + bias)) with f = relu or identity (bias may be null); optionally park the packed values
+// in xres (the residual stream: each thread's private slice). One 16-byte LDS store per tile pair.
 template <int MI, int NI, int WM, int WN, int STRIDE, bool RELU, bool KEEP>
-__device__ __forceinline__ void store_act(const f32x16 (&acc)[MI][NI], const float* __restrict__ bias, char* act, uint4* xres_wg) {
+__device__ __forceinline__ void store_act(const f32x4 (&acc)[MI][NI], const float* __restrict__ bias, char* act, uint4* xres_wg) {
     constexpr int NT = 64 * WM * WN;
-    AZ_LANE_GEO(NI);
+    AZ_LANE_GEO(MI, NI, WN);
     __syncthreads();  // every wave has finished reading act
-    char* wbase = act + (row_base + 4 * h) * STRIDE + (col0 + l31) * 2;
+    char* wbase = act + (row_base + lr) * STRIDE + (col0 + 8 * kq) * 2;
     uint4* xr = xres_wg + t_;
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-        const float bv = bias ? bias[col0 + ni * 32 + l31] : 0.f;
+    for (int p = 0; p < NI / 2; ++p) {
+        float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (bias) {
+            const float4 x0 = *(const float4*)(bias + col0 + 32 * p + 8 * kq), x1 = *(const float4*)(bias + col0 + 32 * p + 8 * kq + 4);
+            bv[0] = x0.x; bv[1] = x0.y; bv[2] = x0.z; bv[3] = x0.w; bv[4] = x1.x; bv[5] = x1.y; bv[6] = x1.z; bv[7] = x1.w;
+        }
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
-            uint32_t pk[8];
+            float v[8];
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                const int off = (mi * 32 + (r & 3) + 8 * (r >> 2)) * STRIDE + ni * 64;
-                float v0 = acc[mi][ni][r] + bv, v1 = acc[mi][ni][r + 1] + bv;
-                if (RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
-                pk[r >> 1] = pack_bf16(v0, v1);
-                *(uint16_t*)(wbase + off) = (uint16_t)(pk[r >> 1] & 0xffffu);
-                *(uint16_t*)(wbase + off + STRIDE) = (uint16_t)(pk[r >> 1] >> 16);
+            for (int r = 0; r < 4; ++r) { v[r] = acc[mi][2 * p][r] + bv[r]; v[4 + r] = acc[mi][2 * p + 1][r] + bv[4 + r]; }
+            if (RELU) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], 0.f);
             }
-            if (KEEP) {
-                xr[(size_t)((mi * NI + ni) * 2) * NT] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-                xr[(size_t)((mi * NI + ni) * 2 + 1) * NT] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
-            }
+            const uint4 pk = make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
+            *(uint4*)(wbase + mi * 16 * STRIDE + p * 64) = pk;
+            if (KEEP) xr[(size_t)(mi * (NI / 2) + p) * NT] = pk;
         }
     }
     __syncthreads();
@@ -238,19 +443,19 @@ __device__ __forceinline__ void store_act(const f32x16 (&acc)[MI][NI], const flo
 // Squeeze-excite gate of one block (model.py:9-22) applied to acc in place. The bf16 image of y is
 // in act; pooled/hidden/scale and the block's SE weights live in `scratch` (the idle weight buffers).
 template <int MI, int NI, int WM, int WN, int C, int STRIDE>
-__device__ __forceinline__ void se_gate(f32x16 (&acc)[MI][NI], const char* act, float* scratch, const uint4* __restrict__ blob, int se_vecs,
+__device__ __forceinline__ void se_gate(f32x4 (&acc)[MI][NI], const char* act, float* scratch, const uint4* __restrict__ blob, int se_vecs,
                                         int hid, int TB, int nb, const TileGeo& g
 #ifdef AZ_STAMP
                                         , unsigned long long* stamp_acc, unsigned long long& stamp_last
 #endif
                                         ) {
     constexpr int NW = WM * WN, NT = 64 * NW;
-    AZ_LANE_GEO(NI);
+    AZ_LANE_GEO(MI, NI, WN);
     const int NP = g.np;
     float* pooled = scratch;                 // [TB][C]
-    float* hidden = pooled + TB * C;         // [TB][hid]
-    float* sc = hidden + TB * hid;           // [TB][C]
-    char* sew = (char*)(sc + TB * C);        // this block's SE weights
+    float* sc = pooled + TB * C;             // [TB][C], 16-byte aligned (C is a multiple of 4)
+    float* hidden = sc + TB * C;             // [TB][hid]
+    char* sew = (char*)(hidden + TB * hid);  // this block's SE weights
     sew += (16 - ((size_t)(sew - (char*)scratch) & 15)) & 15;
     stage_tile<NW>(blob, sew, se_vecs, lane, wave);
     const uint16_t* w1 = (const uint16_t*)sew;   // [hid][C] bf16
@@ -314,90 +519,61 @@ __device__ __forceinline__ void se_gate(f32x16 (&acc)[MI][NI], const char* act, 
     }
     __syncthreads();
     STAMP(11);
-    // A 32-row MFMA tile covers at most two boards when a board has >= 32 points: rows below
-    // `split` belong to board bA, the others to bA + 1.
-    if (NP >= 32) {
+    // every lane owns one position per tile row, so the board (and its gate vector) is per lane and tile row
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-            const int bA = ((row_base + mi * 32) * g.recip_np) >> 16, split = (bA + 1) * NP;
-            float svA[NI], svB[NI];
+    for (int mi = 0; mi < MI; ++mi) {
+        const int row = row_base + mi * 16 + lr;
+        const int b = min((int)((row * g.recip_np) >> 16), nb - 1);   // rows past the valid ones are never read back
+        const float* sb = sc + b * C + col0 + 8 * kq;
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-                const int col = col0 + ni * 32 + l31;
-                svA[ni] = bA < nb ? sc[bA * C + col] : 1.f;
-                svB[ni] = bA + 1 < nb ? sc[(bA + 1) * C + col] : 1.f;
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = row_base + 4 * h + mi * 32 + (r & 3) + 8 * (r >> 2);
-                const bool lower = row < split;
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni) acc[mi][ni][r] *= lower ? svA[ni] : svB[ni];
-            }
-        }
-    } else {
-        for (int b = 0; b < nb; ++b) {
-            const int lo = b * NP, hi = lo + NP;
-            if (lo >= row_base + 32 * MI || hi <= row_base) continue;
-            float sv[NI];
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) sv[ni] = sc[b * C + col0 + ni * 32 + l31];
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = row_base + mi * 32 + 4 * h + (r & 3) + 8 * (r >> 2);
-                    const bool in = row >= lo && row < hi;
-#pragma unroll
-                    for (int ni = 0; ni < NI; ++ni) acc[mi][ni][r] = in ? acc[mi][ni][r] * sv[ni] : acc[mi][ni][r];
-                }
+        for (int p = 0; p < NI / 2; ++p) {
+            const float4 s0 = *(const float4*)(sb + 32 * p), s1 = *(const float4*)(sb + 32 * p + 4);
+            acc[mi][2 * p][0] *= s0.x; acc[mi][2 * p][1] *= s0.y; acc[mi][2 * p][2] *= s0.z; acc[mi][2 * p][3] *= s0.w;
+            acc[mi][2 * p + 1][0] *= s1.x; acc[mi][2 * p + 1][1] *= s1.y; acc[mi][2 * p + 1][2] *= s1.z; acc[mi][2 * p + 1][3] *= s1.w;
         }
     }
 }
 
 // x = relu(y + x) (model.py:40): act <- bf16(x); the new residual goes back to xres when `keep`.
 template <int MI, int NI, int WM, int WN, int STRIDE>
-__device__ __forceinline__ void residual_store(const f32x16 (&acc)[MI][NI], const uint4 (&resv)[MI * NI * 2], char* act, uint4* xres_wg,
-                                               bool keep) {
+__device__ __forceinline__ void residual_store(const f32x4 (&acc)[MI][NI], const uint4 (&resv)[MI * NI / 2], char* act, uint4* xres_wg, bool keep) {
     constexpr int NT = 64 * WM * WN;
-    AZ_LANE_GEO(NI);
+    AZ_LANE_GEO(MI, NI, WN);
     __syncthreads();
-    char* wbase = act + (row_base + 4 * h) * STRIDE + (col0 + l31) * 2;
+    char* wbase = act + (row_base + lr) * STRIDE + (col0 + 8 * kq) * 2;
     uint4* xr = xres_wg + t_;
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
+    for (int p = 0; p < NI / 2; ++p) {
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
-            const uint4 o0 = resv[(mi * NI + ni) * 2], o1 = resv[(mi * NI + ni) * 2 + 1];
-            const uint32_t old[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
-            uint32_t pk[8];
+            const uint4 o = resv[mi * (NI / 2) + p];
+            const uint32_t old[4] = {o.x, o.y, o.z, o.w};
+            uint32_t pk[4];
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                const int off = (mi * 32 + (r & 3) + 8 * (r >> 2)) * STRIDE + ni * 64;
-                const float v0 = fmaxf(acc[mi][ni][r] + bf16_lo(old[r >> 1]), 0.f), v1 = fmaxf(acc[mi][ni][r + 1] + bf16_hi(old[r >> 1]), 0.f);
-                pk[r >> 1] = pack_bf16(v0, v1);
-                *(uint16_t*)(wbase + off) = (uint16_t)(pk[r >> 1] & 0xffffu);
-                *(uint16_t*)(wbase + off + STRIDE) = (uint16_t)(pk[r >> 1] >> 16);
+            for (int r = 0; r < 4; r += 2) {
+                pk[r >> 1] = pack_bf16(fmaxf(acc[mi][2 * p][r] + bf16_lo(old[r >> 1]), 0.f), fmaxf(acc[mi][2 * p][r + 1] + bf16_hi(old[r >> 1]), 0.f));
+                pk[2 + (r >> 1)] = pack_bf16(fmaxf(acc[mi][2 * p + 1][r] + bf16_lo(old[2 + (r >> 1)]), 0.f),
+                                             fmaxf(acc[mi][2 * p + 1][r + 1] + bf16_hi(old[2 + (r >> 1)]), 0.f));
             }
-            if (keep) {
-                xr[(size_t)((mi * NI + ni) * 2) * NT] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-                xr[(size_t)((mi * NI + ni) * 2 + 1) * NT] = make_uint4(pk[4], pk[5], pk[6], pk[7]);
-            }
+            const uint4 v = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+            *(uint4*)(wbase + mi * 16 * STRIDE + p * 64) = v;
+            if (keep) xr[(size_t)(mi * (NI / 2) + p) * NT] = v;
         }
     }
     __syncthreads();
 }
 
-// C channels; WM x WN waves (8 waves = two per SIMD with 256 registers each, or 4 waves = one per SIMD
-// with 512 registers each); NH = padded column count of the fused head 1x1 conv. One workgroup per CU
+// C channels; NW = WM x WN waves of 64 positions-by-C/WN channels; NH = padded channel count of the fused
+// head 1x1 convolution, which all NW waves split by positions only. One workgroup per compute unit
 // (LDS-bound), striding over the board groups.
 template <int C, int WM, int WN, int NH>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_tower(TowerParams P) {
     constexpr int NW = WM * WN, NT = 64 * NW;
-    constexpr int MI = 256 / (WM * 32), NI = C / (WN * 32), NIH = NH / (WN * 32);
-    constexpr int KT = C >= 64 ? 64 : 32;
-    constexpr int STRIDE = 2 * C + 16;
-    constexpr int NV = MI * NI * 2;  // 16-byte vectors of packed bf16 residual per thread
+    constexpr int MI = 256 / (WM * 16), NI = C / (WN * 16);
+    constexpr int MIH = 256 / (NW * 16), NIH = NH / 16;
+    constexpr int STRIDE = 2 * C + 32;
+    constexpr int NV = MI * NI / 2;  // 16-byte vectors of packed bf16 residual per thread
+    static_assert(NI % 2 == 0 && NIH % 2 == 0, "channel tiles are stored in pairs");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* act = smem;
     char* zrow = smem + 256 * STRIDE;
@@ -420,8 +596,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_tower(TowerPara
         g.vrows = nb * P.np;  // valid rows of this workgroup
         __syncthreads();      // the previous item's last LDS reads are done
 
-        // ---- stage 0: feature tile -> act (row stride 2*cin_pad+16)
-        const int in_stride0 = 2 * P.cin_pad + 16;
+        // ---- stage 0: feature tile -> act (row stride 2*cin_pad+32)
+        const int in_stride0 = 2 * P.cin_pad + 32;
         {
             const int ppr = P.cin_pad * 2 / 16;  // 16-byte pieces per row
             const uint4* src = (const uint4*)(P.feat + (size_t)board0 * P.np * P.cin_pad);
@@ -434,26 +610,31 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_tower(TowerPara
         }
         __syncthreads();
 
-        f32x16 acc[MI][NI];
+        f32x4 acc[MI][NI];
         // ---- stem (model.py:61-65)
         zero_acc<MI, NI>(acc);
-        gemm_taps<MI, NI, 32, WM, WN>(acc, P.w_stem, 9 * (P.cin_pad / 32), P.cin_pad / 32, C, true, act, in_stride0, zrow, bbuf, g);
+        {
+            const int kpt = P.cin_pad / 32, nks = (9 * kpt + 1) & ~1;
+            gemm_taps<MI, NI, WM, WN, C, false>(acc, P.w_stem, nks, kpt, 9, true, act, in_stride0, zrow, bbuf, g);
+        }
         STAMP(0);
         store_act<MI, NI, WM, WN, STRIDE, true, true>(acc, P.b_stem, act, xres_wg);
         STAMP(1);
 
         // ---- residual tower (model.py:25-40)
-        const size_t conv_vecs = (size_t)9 * C * C * 2 / 16;
+        constexpr int KPT = C / 32, NKS = (9 * KPT + 1) & ~1;
+        constexpr bool SAME = (KPT % 2) == 0;
+        const size_t conv_vecs = (size_t)NKS * 32 * C * 2 / 16;
         for (int blk = 0; blk < P.blocks; ++blk) {
             zero_acc<MI, NI>(acc);
-            gemm_taps<MI, NI, KT, WM, WN>(acc, P.w_tower + (size_t)(2 * blk) * conv_vecs, 9 * (C / KT), C / KT, C, true, act, STRIDE, zrow,
-                                          bbuf, g);
+            if constexpr (SAME) gemm_conv<MI, NI, WM, WN, C, KPT>(acc, P.w_tower + (size_t)(2 * blk) * conv_vecs, 9, true, act, STRIDE, zrow, bbuf, g);
+            else gemm_taps<MI, NI, WM, WN, C, false>(acc, P.w_tower + (size_t)(2 * blk) * conv_vecs, NKS, KPT, 9, true, act, STRIDE, zrow, bbuf, g);
             STAMP(2);
             store_act<MI, NI, WM, WN, STRIDE, true, false>(acc, P.b_tower + (size_t)(2 * blk) * C, act, xres_wg);
             STAMP(3);
             zero_acc<MI, NI>(acc);
-            gemm_taps<MI, NI, KT, WM, WN>(acc, P.w_tower + (size_t)(2 * blk + 1) * conv_vecs, 9 * (C / KT), C / KT, C, true, act, STRIDE,
-                                          zrow, bbuf, g);
+            if constexpr (SAME) gemm_conv<MI, NI, WM, WN, C, KPT>(acc, P.w_tower + (size_t)(2 * blk + 1) * conv_vecs, 9, true, act, STRIDE, zrow, bbuf, g);
+            else gemm_taps<MI, NI, WM, WN, C, false>(acc, P.w_tower + (size_t)(2 * blk + 1) * conv_vecs, NKS, KPT, 9, true, act, STRIDE, zrow, bbuf, g);
             STAMP(2);
             uint4 resv[NV];   // the block input, fetched now, consumed after the SE gate
             {
@@ -462,15 +643,16 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_tower(TowerPara
                 for (int v = 0; v < NV; ++v) resv[v] = xr[(size_t)v * NT];
             }
             {   // y = acc + bias (kept in registers in float32)
-                AZ_LANE_GEO(NI);
-                const float* bias2 = P.b_tower + (size_t)(2 * blk + 1) * C;
+                AZ_LANE_GEO(MI, NI, WN);
+                const float* bias2 = P.b_tower + (size_t)(2 * blk + 1) * C + col0 + 8 * kq;
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) {
-                    const float bv = bias2[col0 + ni * 32 + l31];
+                for (int p = 0; p < NI / 2; ++p) {
+                    const float4 x0 = *(const float4*)(bias2 + 32 * p), x1 = *(const float4*)(bias2 + 32 * p + 4);
 #pragma unroll
-                    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[mi][ni][r] += bv;
+                    for (int mi = 0; mi < MI; ++mi) {
+                        acc[mi][2 * p][0] += x0.x; acc[mi][2 * p][1] += x0.y; acc[mi][2 * p][2] += x0.z; acc[mi][2 * p][3] += x0.w;
+                        acc[mi][2 * p + 1][0] += x1.x; acc[mi][2 * p + 1][1] += x1.y; acc[mi][2 * p + 1][2] += x1.z; acc[mi][2 * p + 1][3] += x1.w;
+                    }
                 }
             }
             if (P.use_se) {
@@ -487,26 +669,31 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_tower(TowerPara
             STAMP(5);
         }
 
-        // ---- both 1x1 head convolutions as one GEMM (model.py:68-71, :78-81)
+        // ---- both 1x1 head convolutions as one GEMM (model.py:68-71, :78-81); the waves split positions only
         {
-            f32x16 hacc[MI][NIH];
-            zero_acc<MI, NIH>(hacc);
-            gemm_taps<MI, NIH, KT, WM, WN>(hacc, P.w_head, C / KT, C / KT, NH, false, act, STRIDE, zrow, bbuf, g);
+            f32x4 hacc[MIH][NIH];
+            zero_acc<MIH, NIH>(hacc);
+            constexpr int NKH = (KPT + 1) & ~1;
+            if constexpr (SAME) gemm_conv<MIH, NIH, NW, 1, NH, KPT>(hacc, P.w_head, 1, false, act, STRIDE, zrow, bbuf, g);
+            else gemm_taps<MIH, NIH, NW, 1, NH, false>(hacc, P.w_head, NKH, KPT, 1, false, act, STRIDE, zrow, bbuf, g);
             // relu(acc + bias) -> LDS as [row][2q] bf16, then one coalesced copy: the workgroup's slice of hq is contiguous
-            AZ_LANE_GEO(NIH);
+            AZ_LANE_GEO(MIH, NIH, 1);
             const int q2 = 2 * P.q, hstride = q2 * 2 + 16;
             __syncthreads();  // every wave has finished reading act
-            char* hbase = act + (row_base + 4 * h) * hstride + (col0 + l31) * 2;
 #pragma unroll
-            for (int ni = 0; ni < NIH; ++ni) {
-                const int col = col0 + ni * 32 + l31;
-                if (col >= q2) continue;
-                const float bv = P.b_head[col];
+            for (int p = 0; p < NIH / 2; ++p) {
+                const int ch8 = 32 * p + 8 * kq;
+                if (ch8 >= q2) continue;
+                const float4 x0 = *(const float4*)(P.b_head + ch8), x1 = *(const float4*)(P.b_head + ch8 + 4);
+                const float bv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi)
+                for (int mi = 0; mi < MIH; ++mi) {
+                    float v[8];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        *(uint16_t*)(hbase + (mi * 32 + (r & 3) + 8 * (r >> 2)) * hstride + ni * 64) = to_bf16(fmaxf(hacc[mi][ni][r] + bv, 0.f));
+                    for (int r = 0; r < 4; ++r) { v[r] = fmaxf(hacc[mi][2 * p][r] + bv[r], 0.f); v[4 + r] = fmaxf(hacc[mi][2 * p + 1][r] + bv[4 + r], 0.f); }
+                    *(uint4*)(act + (row_base + mi * 16 + lr) * hstride + ch8 * 2) =
+                        make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
+                }
             }
             __syncthreads();
             const int ppr = q2 * 2 / 16;  // 16-byte pieces per row (q2 is a multiple of 8)
@@ -596,7 +783,7 @@ struct MfmaNet {
     int hq_rows = 0;
     uint4* xres = nullptr;   // residual-stream scratch for max_grid workgroups
     int max_grid = 0;
-    int waves = 8;           // waves per workgroup of the C=192 tower (AZ_TOWER_WAVES=4 selects the 512-register variant)
+    int waves = 8;           // waves per workgroup of the C=192 tower (AZ_TOWER_WAVES=4: one wave per SIMD, 512 registers)
     // optional timing of the tower kernel with HIP events on the launch stream
     bool profiling = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -611,16 +798,27 @@ static uint16_t f2bf(float f) {
     return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
 }
 
-// Pack folded weights w[cout][cin][taps] into the LDS B-fragment image, tile after tile:
-// [tile][kstep][half][column n][8 consecutive k], k = tap*cin_pad + ci.
-static std::vector<uint16_t> pack_conv(const std::vector<float>& w, int cout, int cin, int taps, int cin_pad, int ncols, int KT) {
-    const int K = taps * cin_pad;
-    std::vector<uint16_t> out((size_t)K * ncols, 0);
-    for (int k = 0; k < K; ++k) {
-        const int tap = k / cin_pad, ci = k % cin_pad, t = k / KT, kk = k % KT, ks = kk / 16, hh = (kk % 16) / 8, j = kk % 8;
-        if (ci >= cin) continue;
-        for (int nn = 0; nn < cout; ++nn)
-            out[(size_t)t * KT * ncols + (((size_t)ks * 2 + hh) * ncols + nn) * 8 + j] = f2bf(w[((size_t)nn * cin + ci) * taps + tap]);
+// Pack folded weights w[cout][cin][taps] into the LDS image the weight fragments are read from, k-step after
+// k-step (32 input channels of one tap each; the count is padded to an even number with zeros):
+// [k-step][channel tile][lane][8 consecutive input channels]. Lane l of a fragment holds output channel row
+// l & 15 of the tile and input channels 8*(l >> 4).. of the k-step. Tile rows are assigned to output
+// channels so that the MFMA result gives a lane 8 consecutive channels over the tile pair (2p, 2p+1):
+// row r of tile 2p+e is channel 32*p + 8*(r >> 2) + 4*e + (r & 3).
+static std::vector<uint16_t> pack_conv(const std::vector<float>& w, int cout, int cin, int taps, int cin_pad, int ncols) {
+    const int kpt = cin_pad / 32, nks = (taps * kpt + 1) & ~1, ntile = ncols / 16;
+    std::vector<uint16_t> out((size_t)nks * ntile * 64 * 8, 0);
+    for (int s = 0; s < nks; ++s) {
+        const int tap = s / kpt, c0 = (s % kpt) * 32;
+        if (tap >= taps) continue;
+        for (int nt = 0; nt < ntile; ++nt)
+            for (int l = 0; l < 64; ++l) {
+                const int r = l & 15, co = 32 * (nt >> 1) + 8 * (r >> 2) + 4 * (nt & 1) + (r & 3);
+                if (co >= cout) continue;
+                for (int j = 0; j < 8; ++j) {
+                    const int ci = c0 + 8 * (l >> 4) + j;
+                    if (ci < cin) out[(((size_t)s * ntile + nt) * 64 + l) * 8 + j] = f2bf(w[((size_t)co * cin + ci) * taps + tap]);
+                }
+            }
     }
     return out;
 }
@@ -649,9 +847,8 @@ static size_t se_blob_bytes(int C, int hid) {  // per block: w1, w2^T (bf16), b1
 // squeeze-excite scratch (pooled [TB][C], hidden [TB][hid], scale [TB][C],
 // the block's SE weights).
 static size_t tower_lds_bytes(int C, int NH, int TB, int hid) {
-    const int KT = C >= 64 ? 64 : 32;
-    const size_t stride = 2 * C + 16;
-    const size_t tile = (size_t)KT * std::max(C, NH) * 2;
+    const size_t stride = 2 * C + 32;
+    const size_t tile = (size_t)64 * std::max(C, NH) * 2;
     const size_t se = ((size_t)2 * TB * C + (size_t)TB * hid) * 4 + 16 + se_blob_bytes(C, hid);
     return 256 * stride + ((stride + 127) / 128) * 128 + std::max(2 * tile, se);
 }
@@ -665,8 +862,7 @@ int mfma_create(const az_net_config& c, const NetLayout& L, const float* Pm, Mfm
     m->TB = 256 / np;
     m->cin_pad = c.in_planes <= 32 ? 32 : 64;
     m->q = q;
-    m->NH = C == 192 ? 128 : (C == 32 ? 32 : 64);
-    const int KT = C >= 64 ? 64 : 32;
+    m->NH = std::max(32, 2 * q);   // policy q + value q channels, in whole tile pairs
     if (tower_lds_bytes(C, m->NH, m->TB, c.se_hidden) > 160 * 1024) { delete m; return fail(AZ_ERR_ARG, "bf16 MFMA path: LDS budget exceeded"); }
     std::vector<float> w, b;
     TowerParams& P = m->P;
@@ -684,7 +880,7 @@ int mfma_create(const az_net_config& c, const NetLayout& L, const float* Pm, Mfm
 #define TRY(x) if ((rc = (x)) != AZ_OK) { mfma_destroy(m); return rc; }
     {   // stem
         fold_bn(Pm, L.stem_w, L.stem_bn, C, (int64_t)c.in_planes * 9, w, b);
-        std::vector<uint16_t> pk = pack_conv(w, C, c.in_planes, 9, m->cin_pad, C, 32);
+        std::vector<uint16_t> pk = pack_conv(w, C, c.in_planes, 9, m->cin_pad, C);
         uint16_t* d; float* bd;
         TRY(up(m, pk, &d)); TRY(up(m, b, &bd));
         P.w_stem = (const uint4*)d; P.b_stem = bd;
@@ -697,10 +893,10 @@ int mfma_create(const az_net_config& c, const NetLayout& L, const float* Pm, Mfm
         for (int i = 0; i < c.blocks; ++i) {
             const BlockOff& bo = L.blocks[i];
             fold_bn(Pm, bo.conv1, bo.bn1, C, (int64_t)C * 9, w, b);
-            std::vector<uint16_t> pk = pack_conv(w, C, C, 9, C, C, KT);
+            std::vector<uint16_t> pk = pack_conv(w, C, C, 9, C, C);
             all.insert(all.end(), pk.begin(), pk.end()); ball.insert(ball.end(), b.begin(), b.end());
             fold_bn(Pm, bo.conv2, bo.bn2, C, (int64_t)C * 9, w, b);
-            pk = pack_conv(w, C, C, 9, C, C, KT);
+            pk = pack_conv(w, C, C, 9, C, C);
             all.insert(all.end(), pk.begin(), pk.end()); ball.insert(ball.end(), b.begin(), b.end());
             if (c.use_se) {
                 const int hid = c.se_hidden;
@@ -731,7 +927,7 @@ int mfma_create(const az_net_config& c, const NetLayout& L, const float* Pm, Mfm
         std::copy(wv.begin(), wv.end(), wh.begin() + (size_t)q * C);
         std::copy(bp.begin(), bp.end(), bh.begin());
         std::copy(bv.begin(), bv.end(), bh.begin() + q);
-        std::vector<uint16_t> pk = pack_conv(wh, 2 * q, C, 1, C, m->NH, KT);
+        std::vector<uint16_t> pk = pack_conv(wh, 2 * q, C, 1, C, m->NH);
         uint16_t* d; float* f;
         TRY(up(m, pk, &d)); P.w_head = (const uint4*)d;
         TRY(up(m, bh, &f)); P.b_head = f;
@@ -759,11 +955,11 @@ int mfma_create(const az_net_config& c, const NetLayout& L, const float* Pm, Mfm
     hipError_t e = hipSuccess;
     switch (C) {
         case 32: e = hipFuncSetAttribute((const void*)k_tower<32, 8, 1, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); break;
-        case 64: e = hipFuncSetAttribute((const void*)k_tower<64, 4, 2, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); break;
+        case 64: e = hipFuncSetAttribute((const void*)k_tower<64, 4, 2, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); break;
         case 128: e = hipFuncSetAttribute((const void*)k_tower<128, 4, 2, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); break;
         case 192:
-            e = hipFuncSetAttribute((const void*)k_tower<192, 2, 2, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_tower<192, 4, 2, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            e = hipFuncSetAttribute((const void*)k_tower<192, 4, 2, 96>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_tower<192, 2, 2, 96>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             break;
     }
     if (e != hipSuccess) { mfma_destroy(m); return fail(AZ_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); }
@@ -904,11 +1100,11 @@ int mfma_forward(MfmaNet* m, const void* feat, int rows, const int* rows_dev, fl
     }
     switch (C) {
         case 32: hipLaunchKernelGGL((k_tower<32, 8, 1, 32>), dim3(grid), dim3(512), lds, st, P); break;
-        case 64: hipLaunchKernelGGL((k_tower<64, 4, 2, 64>), dim3(grid), dim3(512), lds, st, P); break;
+        case 64: hipLaunchKernelGGL((k_tower<64, 4, 2, 32>), dim3(grid), dim3(512), lds, st, P); break;
         case 128: hipLaunchKernelGGL((k_tower<128, 4, 2, 64>), dim3(grid), dim3(512), lds, st, P); break;
         case 192:
-            if (m->waves == 4) hipLaunchKernelGGL((k_tower<192, 2, 2, 128>), dim3(grid), dim3(256), lds, st, P);
-            else hipLaunchKernelGGL((k_tower<192, 4, 2, 128>), dim3(grid), dim3(512), lds, st, P);
+            if (m->waves == 4) hipLaunchKernelGGL((k_tower<192, 2, 2, 96>), dim3(grid), dim3(256), lds, st, P);
+            else hipLaunchKernelGGL((k_tower<192, 4, 2, 96>), dim3(grid), dim3(512), lds, st, P);
             break;
         default: return fail(AZ_ERR_ARG, "unsupported channel count");
     }

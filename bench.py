@@ -95,7 +95,7 @@ def main():
     ap.add_argument("--games", type=int, default=4096, help="lockstep games per GPU")
     ap.add_argument("--batch", type=int, default=16, help="mcts inference batch (README value 16; upstream default 8)")
     ap.add_argument("--no-dedup", action="store_true", help="evaluate repeated leaves of a batch again, as upstream does")
-    ap.add_argument("--lanes", type=int, default=2, help="independent game lanes (engine + stream each) whose kernels and host work overlap")
+    ap.add_argument("--lanes", type=int, default=3, help="independent game lanes (engine + stream each) whose kernels and host work overlap")
     ap.add_argument("--tower-workgroups", type=int, default=0, help="workgroup limit per tower launch (0: one per CU with 1 lane, 1024 otherwise)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-moves", type=int, default=8)
@@ -180,7 +180,7 @@ def main():
         "games_per_hour_note": "moves/s x 3600 / 162 plies (the 9x9 move cap; random-init self-play runs to the cap or two passes)",
         "games_finished_in_window": int(games),
         "mean_leaf_depth": round(depth_sum / max(1.0, sims), 3),
-        "roofline": {"bound": "mfma", "kernel": "k_tower<192,4,2,128>", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS,
+        "roofline": {"bound": "mfma", "kernel": "k_tower<192,4,2,96>", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS,
                      "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
                      "launches": int(launches), "avg_launch_ms": round(per_launch_ms, 4),
                      "avg_launch_ms_start_to_end": round(tower_ms_sum / max(1, launches), 4),
