@@ -56,6 +56,16 @@ struct TowerParams {
 };
 
 #ifdef AZ_STAMP
+// Loop stamps sit where the loop drains its LDS reads anyway (around the tile barrier, at the tile start).
+#define LSTAMP(slot)                                                                   \
+    do {                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                             \
+        unsigned long long c_;                                                         \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(c_)::"memory");     \
+        __builtin_amdgcn_sched_barrier(0);                                             \
+        g_lacc[slot] += c_ - g_llast;                                                  \
+        g_llast = c_;                                                                  \
+    } while (0)
 #define STAMP(slot)                                                                    \
     do {                                                                               \
         __builtin_amdgcn_sched_barrier(0);                                             \
@@ -67,6 +77,7 @@ struct TowerParams {
     } while (0)
 #else
 #define STAMP(slot) do {} while (0)
+#define LSTAMP(slot) do {} while (0)
 #endif
 
 __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
@@ -277,7 +288,11 @@ __device__ __forceinline__ void gemm_taps(f32x4 (&acc)[MI][NI], const uint4* __r
 // zero row (from a per-lane 9-bit mask of the taps that stay on the board).
 template <int MI, int NI, int WM, int WN, int NCOLS, int KPT>
 __device__ __forceinline__ void gemm_conv(f32x4 (&acc)[MI][NI], const uint4* __restrict__ wg, int ntaps, bool three, const char* act,
-                                          int in_stride, const char* zrow, char* bbuf, const TileGeo& g) {
+                                          int in_stride, const char* zrow, char* bbuf, const TileGeo& g
+#ifdef AZ_STAMP
+                                          , unsigned long long* g_lacc, unsigned long long& g_llast
+#endif
+                                          ) {
     constexpr int NW = WM * WN;
     constexpr int TPT = KPT / 2;                      // tiles per tap
     constexpr int tile_bytes = 64 * NCOLS * 2, nvec = tile_bytes / 16, kstep_bytes = tile_bytes / 2;
@@ -347,6 +362,7 @@ __device__ __forceinline__ void gemm_conv(f32x4 (&acc)[MI][NI], const uint4* __r
             const char* Y = bbuf + (tile_bytes - par);
             const char* xb = X + woff;
             const char* yb = Y + woff;
+            LSTAMP(4);
             // ---- first k-step: fetch the second k-step's fragments meanwhile
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) a1[mi] = *(const bf16x8*)(act + apc[mi] + (u * 128 + 64));
@@ -362,19 +378,25 @@ __device__ __forceinline__ void gemm_conv(f32x4 (&acc)[MI][NI], const uint4* __r
                 if (i < MI + NI) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
             // ---- tile boundary: X is free once every wave has its fragments; tile t+1 is complete in Y
+            LSTAMP(0);
             __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
             __builtin_amdgcn_sched_barrier(0);
-            if (t + 2 < ntiles) {   // tile t+2 (fetched a tile ago) -> X; start fetching tile t+3
+            LSTAMP(1);
+            // tile t+2 (fetched a tile ago) -> X, then fetch tile t+3 into the same registers; both are spread over
+            // the MFMAs below (issued together, 24 KiB of LDS stores and of fetches queue up in the CU's store and
+            // vector-memory paths and hold the in-order instruction streams behind them). Past the last tiles the
+            // last tile is fetched and stored again: X is dead by then, the copies are never read.
+            {
+                const uint4* src = wsrc + (size_t)min(t + 3, ntiles - 1) * nvec;
 #pragma unroll
                 for (int i = 0; i < PW; ++i)
-                    if (!RAGGED || wave + i * NW < NCHUNK) *(uint4*)(X + soff + i * NW * 1024) = stg[i];
-                if (t + 3 < ntiles) {
-#pragma unroll
-                    for (int i = 0; i < PW; ++i)
-                        if (!RAGGED || wave + i * NW < NCHUNK) stg[i] = wsrc[(size_t)(t + 3) * nvec + i * NW * 64];
-                }
+                    if (!RAGGED || wave + i * NW < NCHUNK) {
+                        *(uint4*)(X + soff + i * NW * 1024) = stg[i];
+                        stg[i] = src[i * NW * 64];
+                    }
             }
+            LSTAMP(2);
             // ---- second k-step: fetch the first fragments of the next tile meanwhile (after the last tile: of
             // the zero row and a stale buffer, never used)
 #pragma unroll
@@ -386,10 +408,14 @@ __device__ __forceinline__ void gemm_conv(f32x4 (&acc)[MI][NI], const uint4* __r
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[ni], a1[mi], acc[mi][ni], 0, 0, 0);
+            // the PW global fetches are spread over the MFMAs: issued together they would queue up in the
+            // CU's vector-memory path and hold the in-order instruction streams behind them
 #pragma unroll
             for (int i = 0; i < MI * NI; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 if (i < MI + NI) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                if (i % (MI * NI / PW) == 1 && i / (MI * NI / PW) < PW) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                if (i % (MI * NI / PW) == MI * NI / PW / 2 + 1 && i / (MI * NI / PW) < PW) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
             }
         }
 #pragma unroll
@@ -584,6 +610,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_tower(TowerPara
 #ifdef AZ_STAMP
     unsigned long long stamp_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_last;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
+    unsigned long long lacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long llast = 0;
 #endif
     for (int i = tid; i < STRIDE / 4; i += NT) ((uint32_t*)zrow)[i] = 0;
     TileGeo g;
@@ -627,13 +655,21 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_tower(TowerPara
         const size_t conv_vecs = (size_t)NKS * 32 * C * 2 / 16;
         for (int blk = 0; blk < P.blocks; ++blk) {
             zero_acc<MI, NI>(acc);
+#ifdef AZ_STAMP
+            if constexpr (SAME) gemm_conv<MI, NI, WM, WN, C, KPT>(acc, P.w_tower + (size_t)(2 * blk) * conv_vecs, 9, true, act, STRIDE, zrow, bbuf, g, lacc, llast);
+#else
             if constexpr (SAME) gemm_conv<MI, NI, WM, WN, C, KPT>(acc, P.w_tower + (size_t)(2 * blk) * conv_vecs, 9, true, act, STRIDE, zrow, bbuf, g);
+#endif
             else gemm_taps<MI, NI, WM, WN, C, false>(acc, P.w_tower + (size_t)(2 * blk) * conv_vecs, NKS, KPT, 9, true, act, STRIDE, zrow, bbuf, g);
             STAMP(2);
             store_act<MI, NI, WM, WN, STRIDE, true, false>(acc, P.b_tower + (size_t)(2 * blk) * C, act, xres_wg);
             STAMP(3);
             zero_acc<MI, NI>(acc);
+#ifdef AZ_STAMP
+            if constexpr (SAME) gemm_conv<MI, NI, WM, WN, C, KPT>(acc, P.w_tower + (size_t)(2 * blk + 1) * conv_vecs, 9, true, act, STRIDE, zrow, bbuf, g, lacc, llast);
+#else
             if constexpr (SAME) gemm_conv<MI, NI, WM, WN, C, KPT>(acc, P.w_tower + (size_t)(2 * blk + 1) * conv_vecs, 9, true, act, STRIDE, zrow, bbuf, g);
+#endif
             else gemm_taps<MI, NI, WM, WN, C, false>(acc, P.w_tower + (size_t)(2 * blk + 1) * conv_vecs, NKS, KPT, 9, true, act, STRIDE, zrow, bbuf, g);
             STAMP(2);
             uint4 resv[NV];   // the block input, fetched now, consumed after the SE gate
@@ -674,7 +710,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_tower(TowerPara
             f32x4 hacc[MIH][NIH];
             zero_acc<MIH, NIH>(hacc);
             constexpr int NKH = (KPT + 1) & ~1;
+#ifdef AZ_STAMP
+            if constexpr (SAME) gemm_conv<MIH, NIH, NW, 1, NH, KPT>(hacc, P.w_head, 1, false, act, STRIDE, zrow, bbuf, g, lacc, llast);
+#else
             if constexpr (SAME) gemm_conv<MIH, NIH, NW, 1, NH, KPT>(hacc, P.w_head, 1, false, act, STRIDE, zrow, bbuf, g);
+#endif
             else gemm_taps<MIH, NIH, NW, 1, NH, false>(hacc, P.w_head, NKH, KPT, 1, false, act, STRIDE, zrow, bbuf, g);
             // relu(acc + bias) -> LDS as [row][2q] bf16, then one coalesced copy: the workgroup's slice of hq is contiguous
             AZ_LANE_GEO(MIH, NIH, 1);
@@ -707,29 +747,57 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_tower(TowerPara
     }  // item loop
 #ifdef AZ_STAMP
     if (tid == 0 && P.stamps)
-        for (int i = 0; i < 16; ++i) P.stamps[(size_t)blockIdx.x * 16 + i] = stamp_acc[i];
+        for (int i = 0; i < 16; ++i) P.stamps[(size_t)blockIdx.x * 16 + i] = i >= 12 ? lacc[i == 12 ? 3 : i - 13] : stamp_acc[i];
 #endif
 }
 
 // Policy tail (model.py:72-76, :93-94): 1x1 conv q->2 + BN + ReLU, flatten channel-major, linear.
-__global__ __launch_bounds__(128) void k_policy_tail(const uint16_t* __restrict__ hq, const float* __restrict__ w3, const float* __restrict__ b3,
+// RB boards per workgroup so that the linear layer's weights are fetched once per RB boards; every
+// board's sums run in the same order whichever workgroup and slot it is in.
+template <int RB>
+__global__ __launch_bounds__(256) void k_policy_tail(const uint16_t* __restrict__ hq, const float* __restrict__ w3, const float* __restrict__ b3,
                                                      const float* __restrict__ wfcT, const float* __restrict__ bfc, float* __restrict__ logits,
-                                                     int np, int q, const int* rows_dev) {
-    extern __shared__ float flat[];  // [2*np]
-    const int r = blockIdx.x, A = np + 1, q2 = 2 * q;
-    if (rows_dev && r >= *rows_dev) return;
-    for (int i = threadIdx.x; i < 2 * np; i += blockDim.x) {
-        const int c2 = i / np, pos = i - c2 * np;
-        const uint16_t* src = hq + ((size_t)r * np + pos) * q2;
-        float s = b3[c2];
-        for (int k = 0; k < q; ++k) s = fmaf(w3[c2 * q + k], __uint_as_float((uint32_t)src[k] << 16), s);
-        flat[i] = fmaxf(s, 0.f);
+                                                     int rows, int np, int q, const int* rows_dev) {
+    extern __shared__ float flat[];  // [RB][2*np]
+    if (rows_dev) rows = min(rows, *rows_dev);
+    const int r0 = blockIdx.x * RB, A = np + 1, q2 = 2 * q, F = 2 * np;
+    const int nbk = min(RB, rows - r0);
+    if (nbk <= 0) return;
+    for (int i = threadIdx.x; i < RB * F; i += blockDim.x) {
+        const int b = i / F, k = i - b * F, c2 = k / np, pos = k - c2 * np;
+        float s = 0.f;
+        if (b < nbk) {
+            const uint16_t* src = hq + ((size_t)(r0 + b) * np + pos) * q2;
+            s = b3[c2];
+            for (int kk = 0; kk < q; kk += 8) {
+                const uint4 v = *(const uint4*)(src + kk);
+                const uint32_t u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    s = fmaf(w3[c2 * q + kk + 2 * e], bf16_lo(u[e]), s);
+                    s = fmaf(w3[c2 * q + kk + 2 * e + 1], bf16_hi(u[e]), s);
+                }
+            }
+            s = fmaxf(s, 0.f);
+        }
+        flat[i] = s;
     }
     __syncthreads();
-    for (int a = threadIdx.x; a < A; a += blockDim.x) {
-        float s = bfc[a];
-        for (int i = 0; i < 2 * np; ++i) s = fmaf(wfcT[(size_t)i * A + a], flat[i], s);
-        logits[(size_t)r * A + a] = s;
+    constexpr int RH = RB / 2;   // boards per thread
+    for (int o = threadIdx.x; o < 2 * A; o += blockDim.x) {
+        const int hsel = o / A, a = o - hsel * A;
+        float acc[RH];
+#pragma unroll
+        for (int r = 0; r < RH; ++r) acc[r] = bfc[a];
+        const float* fl = flat + hsel * RH * F;
+        for (int i = 0; i < F; ++i) {
+            const float w = wfcT[(size_t)i * A + a];
+#pragma unroll
+            for (int r = 0; r < RH; ++r) acc[r] = fmaf(w, fl[r * F + i], acc[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < RH; ++r)
+            if (hsel * RH + r < nbk) logits[(size_t)(r0 + hsel * RH + r) * A + a] = acc[r];
     }
 }
 
@@ -771,6 +839,91 @@ __global__ __launch_bounds__(256) void k_value_tail(const uint16_t* __restrict__
     }
 }
 
+// Value tail on the matrix cores: hidden = relu(W4 * flatten(v) + b4) as a [16 boards] x [K = np*q] x [vh] GEMM per
+// workgroup (4 waves, each NTW tiles of 16 hidden units), operands straight from global memory into
+// registers, four k-steps in flight. K is walked position-major (k' = pos*q + ch, the order the head
+// activations are stored in); the weights are packed to match (pack_value_fc). value = tanh(w6 . hidden + b6)
+// with a fixed reduction tree, so a board's value does not depend on its row or on the other rows.
+template <int NTW>
+__global__ __launch_bounds__(256) void k_value_tail_mfma(const uint16_t* __restrict__ hq, const uint4* __restrict__ w4p, const float* __restrict__ b4p,
+                                                         const float* __restrict__ w6p, const float* __restrict__ b6, float* __restrict__ values,
+                                                         int rows, int np, int q, int nks, int ntiles, unsigned recip_qc, const int* rows_dev) {
+    __shared__ float red[4][16];
+    if (rows_dev) rows = min(rows, *rows_dev);
+    const int r0 = blockIdx.x * 16;
+    if (r0 >= rows) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, kq = lane >> 4;
+    const int row = min(r0 + li, rows - 1);
+    const int qc = q >> 3, nfrag = np * qc;
+    const uint16_t* abase = hq + (size_t)row * np * 2 * q + q;   // the value half of this board's head activations
+    const uint4* bbase = w4p + (size_t)wave * 64 + lane;         // tile `wave` of k-step 0; tiles wave + 4t follow at +256t vectors
+    const size_t kstride = (size_t)ntiles * 64;
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    auto load_a = [&](int s) -> uint4 {
+        const int f = 4 * s + kq;
+        if (f >= nfrag) return zero4;
+        const int pos = (int)(((unsigned)f * recip_qc) >> 16), chunk = f - pos * qc;
+        return *(const uint4*)(abase + (size_t)pos * 2 * q + chunk * 8);
+    };
+    f32x4 acc[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    uint4 a[4], b[4][NTW];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        a[d] = zero4;
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) b[d][t] = zero4;
+        if (d < nks) {
+            a[d] = load_a(d);
+#pragma unroll
+            for (int t = 0; t < NTW; ++t)
+                if (wave + 4 * t < ntiles) b[d][t] = bbase[(size_t)d * kstride + t * 256];
+        }
+    }
+    for (int s = 0; s < nks; s += 4) {
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            if (s + d < nks) {
+#pragma unroll
+                for (int t = 0; t < NTW; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[d]), __builtin_bit_cast(bf16x8, b[d][t]), acc[t], 0, 0, 0);
+                if (s + d + 4 < nks) {
+                    a[d] = load_a(s + d + 4);
+#pragma unroll
+                    for (int t = 0; t < NTW; ++t)
+                        if (wave + 4 * t < ntiles) b[d][t] = bbase[(size_t)(s + d + 4) * kstride + t * 256];
+                }
+            }
+        }
+    }
+    // lane: hidden unit (wave + 4t)*16 + li of boards 4*kq .. 4*kq+3
+    float part[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+        const int j = (wave + 4 * t) * 16 + li;
+        const float bb = wave + 4 * t < ntiles ? b4p[j] : 0.f, ww = wave + 4 * t < ntiles ? w6p[j] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[r] = fmaf(ww, fmaxf(acc[t][r] + bb, 0.f), part[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        part[r] += __shfl_xor(part[r], 1);
+        part[r] += __shfl_xor(part[r], 2);
+        part[r] += __shfl_xor(part[r], 4);
+        part[r] += __shfl_xor(part[r], 8);
+    }
+    if (li == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][4 * kq + r] = part[r];
+    }
+    __syncthreads();
+    if (threadIdx.x < 16 && r0 + (int)threadIdx.x < rows) {
+        const int i = threadIdx.x;
+        values[r0 + i] = tanhf(((red[0][i] + red[1][i]) + (red[2][i] + red[3][i])) + b6[0]);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ host
 struct MfmaNet {
     az_net_config cfg;
@@ -779,6 +932,10 @@ struct MfmaNet {
     TowerParams P;
     float *w3, *b3, *wfcT, *bfc, *b4, *w6, *b6;
     uint16_t* w4T;
+    uint16_t* w4p = nullptr;   // value fc1 packed for k_value_tail_mfma (null: hidden size too large, scalar tail)
+    float *b4p = nullptr, *w6p = nullptr;
+    int v_nks = 0, v_ntiles = 0;
+    unsigned v_recip = 0;
     uint16_t* hq = nullptr;
     int hq_rows = 0;
     uint4* xres = nullptr;   // residual-stream scratch for max_grid workgroups
@@ -948,6 +1105,31 @@ int mfma_create(const az_net_config& c, const NetLayout& L, const float* Pm, Mfm
         TRY(up(m, std::vector<float>(Pm + L.vh4_b, Pm + L.vh4_b + vh), &m->b4));
         TRY(up(m, std::vector<float>(Pm + L.vh6_w, Pm + L.vh6_w + vh), &m->w6));
         TRY(up(m, std::vector<float>(Pm + L.vh6_b, Pm + L.vh6_b + 1), &m->b6));
+        if (vh <= 256) {
+            // [k-step][unit tile][lane][8]: lane l holds unit tile*16 + (l & 15), k' = 32*s + 8*(l >> 4) + e with
+            // k' = pos*q + ch standing for column ch*np + pos of value_head.4 (flatten is channel-major, model.py:82)
+            const int ntiles = (vh + 15) / 16, nks = (K + 31) / 32, qc = q / 8;
+            std::vector<uint16_t> pk((size_t)nks * ntiles * 64 * 8, 0);
+            for (int s2 = 0; s2 < nks; ++s2)
+                for (int t = 0; t < ntiles; ++t)
+                    for (int l = 0; l < 64; ++l) {
+                        const int j = t * 16 + (l & 15);
+                        if (j >= vh) continue;
+                        for (int e = 0; e < 8; ++e) {
+                            const int kp = 32 * s2 + 8 * (l >> 4) + e;
+                            if (kp >= K) continue;
+                            const int pos = kp / q, ch = kp % q;
+                            pk[(((size_t)s2 * ntiles + t) * 64 + l) * 8 + e] = f2bf(Pm[L.vh4_w + (int64_t)j * K + (int64_t)ch * np + pos]);
+                        }
+                    }
+            std::vector<float> b4p((size_t)ntiles * 16, 0.f), w6p((size_t)ntiles * 16, 0.f);
+            for (int j = 0; j < vh; ++j) { b4p[j] = Pm[L.vh4_b + j]; w6p[j] = Pm[L.vh6_w + j]; }
+            TRY(up(m, pk, &m->w4p)); TRY(up(m, b4p, &m->b4p)); TRY(up(m, w6p, &m->w6p));
+            m->v_nks = nks; m->v_ntiles = ntiles;
+            m->v_recip = (65536 + qc - 1) / qc;
+            for (int f = 0; f < np * qc + 8; ++f)
+                if ((((unsigned)f * m->v_recip) >> 16) != (unsigned)(f / qc)) { mfma_destroy(m); return fail(AZ_ERR_ARG, "reciprocal division check failed (value tail)"); }
+        }
     }
 #undef TRY
     // opt in to the large dynamic LDS size once
@@ -1109,10 +1291,22 @@ int mfma_forward(MfmaNet* m, const void* feat, int rows, const int* rows_dev, fl
         default: return fail(AZ_ERR_ARG, "unsupported channel count");
     }
     if (ev) (void)hipEventRecord(ev->second, st);
-    hipLaunchKernelGGL(k_policy_tail, dim3(rows), dim3(128), (size_t)2 * np * 4, st, m->hq, m->w3, m->b3, m->wfcT, m->bfc, logits, np, q, rows_dev);
-    const size_t vt = ((size_t)4 * q * np + 4 * c.value_hidden) * 4;
-    hipLaunchKernelGGL((k_value_tail<4>), dim3((rows + 3) / 4), dim3(256), vt, st, m->hq, m->w4T, m->b4, m->w6, m->b6, values, rows, np, q,
-                       c.value_hidden, rows_dev);
+    hipLaunchKernelGGL((k_policy_tail<8>), dim3((rows + 7) / 8), dim3(256), (size_t)8 * 2 * np * 4, st, m->hq, m->w3, m->b3, m->wfcT, m->bfc, logits, rows,
+                       np, q, rows_dev);
+    if (m->w4p) {
+        const dim3 vg((rows + 15) / 16);
+        const uint4* wp = (const uint4*)m->w4p;
+        switch ((m->v_ntiles + 3) / 4) {
+            case 1: hipLaunchKernelGGL((k_value_tail_mfma<1>), vg, dim3(256), 0, st, m->hq, wp, m->b4p, m->w6p, m->b6, values, rows, np, q, m->v_nks, m->v_ntiles, m->v_recip, rows_dev); break;
+            case 2: hipLaunchKernelGGL((k_value_tail_mfma<2>), vg, dim3(256), 0, st, m->hq, wp, m->b4p, m->w6p, m->b6, values, rows, np, q, m->v_nks, m->v_ntiles, m->v_recip, rows_dev); break;
+            case 3: hipLaunchKernelGGL((k_value_tail_mfma<3>), vg, dim3(256), 0, st, m->hq, wp, m->b4p, m->w6p, m->b6, values, rows, np, q, m->v_nks, m->v_ntiles, m->v_recip, rows_dev); break;
+            default: hipLaunchKernelGGL((k_value_tail_mfma<4>), vg, dim3(256), 0, st, m->hq, wp, m->b4p, m->w6p, m->b6, values, rows, np, q, m->v_nks, m->v_ntiles, m->v_recip, rows_dev); break;
+        }
+    } else {
+        const size_t vt = ((size_t)4 * q * np + 4 * c.value_hidden) * 4;
+        hipLaunchKernelGGL((k_value_tail<4>), dim3((rows + 3) / 4), dim3(256), vt, st, m->hq, m->w4T, m->b4, m->w6, m->b6, values, rows, np, q,
+                           c.value_hidden, rows_dev);
+    }
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return fail(AZ_ERR_HIP, std::string("bf16 forward: ") + hipGetErrorString(err));
 #ifdef AZ_STAMP
@@ -1123,10 +1317,10 @@ int mfma_forward(MfmaNet* m, const void* feat, int rows, const int* rows_dev, fl
         double sum[16] = {0};
         for (int g = 0; g < grid; ++g) for (int i = 0; i < 16; ++i) sum[i] += (double)hst[(size_t)g * 16 + i];
         const char* nm[16] = {"load+stem gemm", "stem epilogue", "conv gemm (2/blk)", "conv1 epilogue", "SE scale", "residual epilogue", "head gemm+store",
-                              "resv issue+bias+y image", "SE pooling", "SE wait+sync", "SE fc1", "SE fc2", "-", "-", "-", "-"};
+                              "resv issue+bias+y image", "SE pooling", "SE wait+sync", "SE fc1", "SE fc2", "[loop] wait+ds_write", "[loop] 1st half", "[loop] barrier", "[loop] load issue"};
         double tot = 0; for (int i = 0; i < 12; ++i) tot += sum[i];
         fprintf(stderr, "[AZ_STAMP] rows=%d grid=%d mean cycles/WG=%.0f\n", rows, grid, tot / grid);
-        for (int i = 0; i < 12; ++i) fprintf(stderr, "  %-20s %10.0f  %5.1f%%\n", nm[i], sum[i] / grid, 100.0 * sum[i] / tot);
+        for (int i = 0; i < 16; ++i) fprintf(stderr, "  %-20s %10.0f  %5.1f%%\n", nm[i], sum[i] / grid, 100.0 * sum[i] / tot);
     }
 #endif
     return AZ_OK;
