@@ -56,16 +56,6 @@ struct TowerParams {
 };
 
 #ifdef AZ_STAMP
-// Loop stamps sit where the loop drains its LDS reads anyway (around the tile barrier, at the tile start).
-#define LSTAMP(slot)                                                                   \
-    do {                                                                               \
-        __builtin_amdgcn_sched_barrier(0);                                             \
-        unsigned long long c_;                                                         \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(c_)::"memory");     \
-        __builtin_amdgcn_sched_barrier(0);                                             \
-        g_lacc[slot] += c_ - g_llast;                                                  \
-        g_llast = c_;                                                                  \
-    } while (0)
 #define STAMP(slot)                                                                    \
     do {                                                                               \
         __builtin_amdgcn_sched_barrier(0);                                             \
@@ -77,7 +67,6 @@ struct TowerParams {
     } while (0)
 #else
 #define STAMP(slot) do {} while (0)
-#define LSTAMP(slot) do {} while (0)
 #endif
 
 __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
@@ -196,7 +185,9 @@ __device__ __forceinline__ void gemm_taps(f32x4 (&acc)[MI][NI], const uint4* __r
         ++cc;
     }
     if (cc >= kpt) { cc = 0; ++tap; }
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");   // tiles 0 and 1 have landed; the register fetch may still fly
+    // tiles 0 and 1 have landed; the PW register fetches issued after them may still fly (the counter retires in order)
+    if (!RAGGED && ntiles > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     bf16x8 a0[MI], b0[NI], a1[MI], b1[NI];
 #pragma unroll
@@ -288,11 +279,7 @@ __device__ __forceinline__ void gemm_taps(f32x4 (&acc)[MI][NI], const uint4* __r
 // zero row (from a per-lane 9-bit mask of the taps that stay on the board).
 template <int MI, int NI, int WM, int WN, int NCOLS, int KPT>
 __device__ __forceinline__ void gemm_conv(f32x4 (&acc)[MI][NI], const uint4* __restrict__ wg, int ntaps, bool three, const char* act,
-                                          int in_stride, const char* zrow, char* bbuf, const TileGeo& g
-#ifdef AZ_STAMP
-                                          , unsigned long long* g_lacc, unsigned long long& g_llast
-#endif
-                                          ) {
+                                          int in_stride, const char* zrow, char* bbuf, const TileGeo& g) {
     constexpr int NW = WM * WN;
     constexpr int TPT = KPT / 2;                      // tiles per tap
     constexpr int tile_bytes = 64 * NCOLS * 2, nvec = tile_bytes / 16, kstep_bytes = tile_bytes / 2;
@@ -345,7 +332,9 @@ __device__ __forceinline__ void gemm_conv(f32x4 (&acc)[MI][NI], const uint4* __r
         for (int mi = 0; mi < MI; ++mi) out[mi] = (vmask[mi] & bit) ? roff[mi] + shift : zoff;
     };
     tap_offsets(apc, 0);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");   // tiles 0 and 1 have landed; the register fetch may still fly
+    // tiles 0 and 1 have landed; the PW register fetches issued after them may still fly (the counter retires in order)
+    if (!RAGGED && ntiles > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     bf16x8 a0[MI], b0[NI], a1[MI], b1[NI];
 #pragma unroll
@@ -362,7 +351,6 @@ __device__ __forceinline__ void gemm_conv(f32x4 (&acc)[MI][NI], const uint4* __r
             const char* Y = bbuf + (tile_bytes - par);
             const char* xb = X + woff;
             const char* yb = Y + woff;
-            LSTAMP(4);
             // ---- first k-step: fetch the second k-step's fragments meanwhile
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) a1[mi] = *(const bf16x8*)(act + apc[mi] + (u * 128 + 64));
@@ -378,11 +366,9 @@ __device__ __forceinline__ void gemm_conv(f32x4 (&acc)[MI][NI], const uint4* __r
                 if (i < MI + NI) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
             // ---- tile boundary: X is free once every wave has its fragments; tile t+1 is complete in Y
-            LSTAMP(0);
             __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
             __builtin_amdgcn_sched_barrier(0);
-            LSTAMP(1);
             // tile t+2 (fetched a tile ago) -> X, then fetch tile t+3 into the same registers; both are spread over
             // the MFMAs below (issued together, 24 KiB of LDS stores and of fetches queue up in the CU's store and
             // vector-memory paths and hold the in-order instruction streams behind them). Past the last tiles the
@@ -396,7 +382,6 @@ __device__ __forceinline__ void gemm_conv(f32x4 (&acc)[MI][NI], const uint4* __r
                         stg[i] = src[i * NW * 64];
                     }
             }
-            LSTAMP(2);
             // ---- second k-step: fetch the first fragments of the next tile meanwhile (after the last tile: of
             // the zero row and a stale buffer, never used)
 #pragma unroll
@@ -519,8 +504,22 @@ __device__ __forceinline__ void se_gate(f32x4 (&acc)[MI][NI], const char* act, f
         for (int o = t_ >> 3; o < nb * hid; o += NT / 8) {
             const int b = o / hid, j = o - b * hid;
             float s = 0.f;
+            if constexpr ((C / 8) % 8 == 0) {   // a contiguous run of C/8 channels per lane, 16-byte LDS reads
+                const uint16_t* wr = w1 + j * C + sub * (C / 8);
+                const float* pr = pooled + b * C + sub * (C / 8);
 #pragma unroll
-            for (int ch = 0; ch < C; ch += 8) s = fmaf(__uint_as_float((uint32_t)w1[j * C + ch + sub] << 16), pooled[b * C + ch + sub], s);
+                for (int c = 0; c < C / 8; c += 8) {
+                    const uint4 w = *(const uint4*)(wr + c);
+                    const float4 p0 = *(const float4*)(pr + c), p1 = *(const float4*)(pr + c + 4);
+                    s = fmaf(bf16_lo(w.x), p0.x, s); s = fmaf(bf16_hi(w.x), p0.y, s);
+                    s = fmaf(bf16_lo(w.y), p0.z, s); s = fmaf(bf16_hi(w.y), p0.w, s);
+                    s = fmaf(bf16_lo(w.z), p1.x, s); s = fmaf(bf16_hi(w.z), p1.y, s);
+                    s = fmaf(bf16_lo(w.w), p1.z, s); s = fmaf(bf16_hi(w.w), p1.w, s);
+                }
+            } else {
+#pragma unroll
+                for (int ch = 0; ch < C; ch += 8) s = fmaf(__uint_as_float((uint32_t)w1[j * C + ch + sub] << 16), pooled[b * C + ch + sub], s);
+            }
             s += __shfl_xor(s, 1);
             s += __shfl_xor(s, 2);
             s += __shfl_xor(s, 4);
@@ -610,8 +609,6 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_tower(TowerPara
 #ifdef AZ_STAMP
     unsigned long long stamp_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_last;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
-    unsigned long long lacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long llast = 0;
 #endif
     for (int i = tid; i < STRIDE / 4; i += NT) ((uint32_t*)zrow)[i] = 0;
     TileGeo g;
@@ -655,21 +652,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_tower(TowerPara
         const size_t conv_vecs = (size_t)NKS * 32 * C * 2 / 16;
         for (int blk = 0; blk < P.blocks; ++blk) {
             zero_acc<MI, NI>(acc);
-#ifdef AZ_STAMP
-            if constexpr (SAME) gemm_conv<MI, NI, WM, WN, C, KPT>(acc, P.w_tower + (size_t)(2 * blk) * conv_vecs, 9, true, act, STRIDE, zrow, bbuf, g, lacc, llast);
-#else
             if constexpr (SAME) gemm_conv<MI, NI, WM, WN, C, KPT>(acc, P.w_tower + (size_t)(2 * blk) * conv_vecs, 9, true, act, STRIDE, zrow, bbuf, g);
-#endif
             else gemm_taps<MI, NI, WM, WN, C, false>(acc, P.w_tower + (size_t)(2 * blk) * conv_vecs, NKS, KPT, 9, true, act, STRIDE, zrow, bbuf, g);
             STAMP(2);
             store_act<MI, NI, WM, WN, STRIDE, true, false>(acc, P.b_tower + (size_t)(2 * blk) * C, act, xres_wg);
             STAMP(3);
             zero_acc<MI, NI>(acc);
-#ifdef AZ_STAMP
-            if constexpr (SAME) gemm_conv<MI, NI, WM, WN, C, KPT>(acc, P.w_tower + (size_t)(2 * blk + 1) * conv_vecs, 9, true, act, STRIDE, zrow, bbuf, g, lacc, llast);
-#else
             if constexpr (SAME) gemm_conv<MI, NI, WM, WN, C, KPT>(acc, P.w_tower + (size_t)(2 * blk + 1) * conv_vecs, 9, true, act, STRIDE, zrow, bbuf, g);
-#endif
             else gemm_taps<MI, NI, WM, WN, C, false>(acc, P.w_tower + (size_t)(2 * blk + 1) * conv_vecs, NKS, KPT, 9, true, act, STRIDE, zrow, bbuf, g);
             STAMP(2);
             uint4 resv[NV];   // the block input, fetched now, consumed after the SE gate
@@ -710,11 +699,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_tower(TowerPara
             f32x4 hacc[MIH][NIH];
             zero_acc<MIH, NIH>(hacc);
             constexpr int NKH = (KPT + 1) & ~1;
-#ifdef AZ_STAMP
-            if constexpr (SAME) gemm_conv<MIH, NIH, NW, 1, NH, KPT>(hacc, P.w_head, 1, false, act, STRIDE, zrow, bbuf, g, lacc, llast);
-#else
             if constexpr (SAME) gemm_conv<MIH, NIH, NW, 1, NH, KPT>(hacc, P.w_head, 1, false, act, STRIDE, zrow, bbuf, g);
-#endif
             else gemm_taps<MIH, NIH, NW, 1, NH, false>(hacc, P.w_head, NKH, KPT, 1, false, act, STRIDE, zrow, bbuf, g);
             // relu(acc + bias) -> LDS as [row][2q] bf16, then one coalesced copy: the workgroup's slice of hq is contiguous
             AZ_LANE_GEO(MIH, NIH, 1);
@@ -747,7 +732,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_tower(TowerPara
     }  // item loop
 #ifdef AZ_STAMP
     if (tid == 0 && P.stamps)
-        for (int i = 0; i < 16; ++i) P.stamps[(size_t)blockIdx.x * 16 + i] = i >= 12 ? lacc[i == 12 ? 3 : i - 13] : stamp_acc[i];
+        for (int i = 0; i < 16; ++i) P.stamps[(size_t)blockIdx.x * 16 + i] = stamp_acc[i];
 #endif
 }
 
@@ -940,7 +925,6 @@ struct MfmaNet {
     int hq_rows = 0;
     uint4* xres = nullptr;   // residual-stream scratch for max_grid workgroups
     int max_grid = 0;
-    int waves = 8;           // waves per workgroup of the C=192 tower (AZ_TOWER_WAVES=4: one wave per SIMD, 512 registers)
     // optional timing of the tower kernel with HIP events on the launch stream
     bool profiling = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -1139,16 +1123,12 @@ int mfma_create(const az_net_config& c, const NetLayout& L, const float* Pm, Mfm
         case 32: e = hipFuncSetAttribute((const void*)k_tower<32, 8, 1, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); break;
         case 64: e = hipFuncSetAttribute((const void*)k_tower<64, 4, 2, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); break;
         case 128: e = hipFuncSetAttribute((const void*)k_tower<128, 4, 2, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); break;
-        case 192:
-            e = hipFuncSetAttribute((const void*)k_tower<192, 4, 2, 96>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_tower<192, 2, 2, 96>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            break;
+        case 192: e = hipFuncSetAttribute((const void*)k_tower<192, 4, 2, 96>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); break;
     }
     if (e != hipSuccess) { mfma_destroy(m); return fail(AZ_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); }
     const size_t vt = ((size_t)4 * q * np + 4 * c.value_hidden) * 4;
     e = hipFuncSetAttribute((const void*)k_value_tail<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vt);
     if (e != hipSuccess) { mfma_destroy(m); return fail(AZ_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); }
-    if (const char* w = getenv("AZ_TOWER_WAVES")) m->waves = atoi(w) == 4 ? 4 : 8;
     {   // one workgroup per CU (LDS-bound), each striding over the board groups
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, c.device) != hipSuccess) { mfma_destroy(m); return fail(AZ_ERR_HIP, "hipGetDeviceProperties"); }
@@ -1284,10 +1264,7 @@ int mfma_forward(MfmaNet* m, const void* feat, int rows, const int* rows_dev, fl
         case 32: hipLaunchKernelGGL((k_tower<32, 8, 1, 32>), dim3(grid), dim3(512), lds, st, P); break;
         case 64: hipLaunchKernelGGL((k_tower<64, 4, 2, 32>), dim3(grid), dim3(512), lds, st, P); break;
         case 128: hipLaunchKernelGGL((k_tower<128, 4, 2, 64>), dim3(grid), dim3(512), lds, st, P); break;
-        case 192:
-            if (m->waves == 4) hipLaunchKernelGGL((k_tower<192, 2, 2, 96>), dim3(grid), dim3(256), lds, st, P);
-            else hipLaunchKernelGGL((k_tower<192, 4, 2, 96>), dim3(grid), dim3(512), lds, st, P);
-            break;
+        case 192: hipLaunchKernelGGL((k_tower<192, 4, 2, 96>), dim3(grid), dim3(512), lds, st, P); break;
         default: return fail(AZ_ERR_ARG, "unsupported channel count");
     }
     if (ev) (void)hipEventRecord(ev->second, st);
@@ -1317,10 +1294,10 @@ int mfma_forward(MfmaNet* m, const void* feat, int rows, const int* rows_dev, fl
         double sum[16] = {0};
         for (int g = 0; g < grid; ++g) for (int i = 0; i < 16; ++i) sum[i] += (double)hst[(size_t)g * 16 + i];
         const char* nm[16] = {"load+stem gemm", "stem epilogue", "conv gemm (2/blk)", "conv1 epilogue", "SE scale", "residual epilogue", "head gemm+store",
-                              "resv issue+bias+y image", "SE pooling", "SE wait+sync", "SE fc1", "SE fc2", "[loop] wait+ds_write", "[loop] 1st half", "[loop] barrier", "[loop] load issue"};
+                              "resv issue+bias+y image", "SE pooling", "SE wait+sync", "SE fc1", "SE fc2", "-", "-", "-", "-"};
         double tot = 0; for (int i = 0; i < 12; ++i) tot += sum[i];
         fprintf(stderr, "[AZ_STAMP] rows=%d grid=%d mean cycles/WG=%.0f\n", rows, grid, tot / grid);
-        for (int i = 0; i < 16; ++i) fprintf(stderr, "  %-20s %10.0f  %5.1f%%\n", nm[i], sum[i] / grid, 100.0 * sum[i] / tot);
+        for (int i = 0; i < 12; ++i) fprintf(stderr, "  %-20s %10.0f  %5.1f%%\n", nm[i], sum[i] / grid, 100.0 * sum[i] / tot);
     }
 #endif
     return AZ_OK;
