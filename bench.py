@@ -38,6 +38,18 @@ def tower_flops_per_position(n=9, cin=21, ch=CH, blocks=BLOCKS):
     return 2.0 * macs
 
 
+def tower_traffic_per_launch(rows_per_launch):
+    """HBM-side bytes per tower launch from the committed PMC summary (separate FETCH_SIZE / WRITE_SIZE passes of
+    this benchmark, collected offline: counters cannot be read from inside the run), scaled by rows."""
+    path = os.path.join(ROOT, "profiles", "r01c_tower_hbm_traffic.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        return round(d["bytes_per_launch"] / d.get("rows_per_launch", 1364.3) * rows_per_launch)
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_worker(args):
     """One CPU self-play worker: oracle search + torch CPU network, 1 thread (train.py:357-392 topology)."""
     wid, moves, batch, seed = args
@@ -181,7 +193,10 @@ def main():
         "games_finished_in_window": int(games),
         "mean_leaf_depth": round(depth_sum / max(1.0, sims), 3),
         "roofline": {"bound": "mfma", "kernel": "k_tower<192,4,2,96>", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS,
-                     "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                     "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
+                     "traffic": tower_traffic_per_launch(tower_rows / max(1, launches)),
+                     "traffic_note": "bytes per launch on the L2's memory side (Infinity Cache hits included), PMC passes in profiles/r01c_tower_hbm_traffic.json; "
+                                     "mostly the bf16 residual stream parked per workgroup between the two convolutions of a block",
                      "launches": int(launches), "avg_launch_ms": round(per_launch_ms, 4),
                      "avg_launch_ms_start_to_end": round(tower_ms_sum / max(1, launches), 4),
                      "timing": "HIP events around every tower launch on its stream; launches of different lanes overlap, so "

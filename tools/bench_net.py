@@ -1,7 +1,7 @@
 """Micro-benchmark of the bf16 network forward (rows positions) with HIP events."""
 import sys, time
 import torch
-sys.path.insert(0, "tests")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from alphazero_amd.model import AlphaZeroNet
 
 def main():
