@@ -67,6 +67,7 @@ SIGNATURES = {
     "az_net_profile_spans": (_I32, [_VP, _VP, C.c_int64, C.POINTER(C.c_int64)]),
     "az_net_set_tower_workgroups": (_I32, [_VP, _I32]),
     "az_net_profile": (_I32, [_VP, _I32, C.POINTER(C.c_double), C.POINTER(_I64), C.POINTER(_I64)]),
+    "az_replay_gather": (_I32, [_VP, _VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _VP, _VP, _VP]),
     "az_rng_create": (_I32, [_I32, C.POINTER(_VP)]),
     "az_rng_destroy": (_I32, [_VP]),
     "az_rng_seed": (_I32, [_VP, _I32, C.c_uint32]),

@@ -10,6 +10,7 @@ run(num_games) returns the tuple run_selfplay returns (train.py:395-463):
 from __future__ import annotations
 
 import ctypes as C
+import random
 import time
 from dataclasses import dataclass
 
@@ -41,10 +42,43 @@ class SelfPlayConfig:
     temp_end: float = 0.05
     resign_threshold: float = 0.98
     disable_resign: bool = False
+    opening_book_prob: float = 0.0
+    opening_book_max_moves: int = 0
 
     @classmethod
     def from_train_config(cls, cfg) -> "SelfPlayConfig":
         return cls(**{k: getattr(cfg, k) for k in cls.__dataclass_fields__ if hasattr(cfg, k)})
+
+
+def opening_book_lines(board_size: int):
+    """train.py:266-288: four short centre openings, duplicates and off-board points dropped."""
+    if board_size < 5:
+        return []
+    c = board_size // 2
+    lo, hi = max(0, c - 1), min(board_size - 1, c + 1)
+    raw = [[(c, c), (lo, c), (c, lo), (hi, c), (c, hi)],
+           [(c, c), (c, lo), (lo, c), (c, hi), (hi, c)],
+           [(lo, lo), (hi, hi), (lo, hi), (hi, lo), (c, c)],
+           [(lo, c), (hi, c), (c, lo), (c, hi), (c, c)]]
+    lines = []
+    for line in raw:
+        pts = [p for p in dict.fromkeys(line) if 0 <= p[0] < board_size and 0 <= p[1] < board_size]
+        if pts:
+            lines.append(pts)
+    return lines
+
+
+def choose_opening(board_size: int, cfg, rng=random):
+    """The draws of train.py:291-302 from `rng` (the global `random` module upstream): the book moves to try."""
+    if cfg.opening_book_prob <= 0.0 or cfg.opening_book_max_moves <= 0:
+        return []
+    if rng.random() >= cfg.opening_book_prob:
+        return []
+    lines = opening_book_lines(board_size)
+    if not lines:
+        return []
+    line = rng.choice(lines)
+    return line[: min(len(line), cfg.opening_book_max_moves)]
 
 
 class HostRng:
@@ -163,6 +197,33 @@ class _Lane:
         self.log_base = self.step_no         # step index of log[0]
         self.start_step = np.full(G, self.step_no, np.int64)   # first step of the game in each slot
         self.inflight = None
+        self._open_games(np.nonzero(self.game_id >= 0)[0])
+
+    def _open_games(self, slots):
+        """Opening-book moves of the games just dealt to `slots` (train.py:291-311). A game's book draws come
+        from random.Random(seed0 + id): what `random` yields after upstream's set_seed(seed0 + id)."""
+        cfg = self.o.cfg
+        if cfg.opening_book_prob <= 0.0 or cfg.opening_book_max_moves <= 0 or len(slots) == 0:
+            return
+        n = cfg.board_size
+        lines = {int(s): choose_opening(n, cfg, random.Random(self.o.seed0 + int(self.game_id[s]))) for s in slots}
+        live = {s for s, ln in lines.items() if ln}
+        with torch.cuda.stream(self.stream):
+            for k in range(max((len(ln) for ln in lines.values()), default=0)):
+                actions = np.full(self.G, -1, np.int32)
+                for s in list(live):
+                    if k < len(lines[s]):
+                        actions[s] = lines[s][k][0] * n + lines[s][k][1]
+                    else:
+                        live.discard(s)
+                if not live:
+                    break
+                st = self.eng.play(torch.from_numpy(actions), raise_on_illegal=False).cpu().numpy()
+                for s in list(live):
+                    if st[s] != 0:
+                        live.discard(s)      # an illegal book move ends the line without being played
+                    else:
+                        self.move_idx[s] += 1
 
     def busy(self) -> bool:
         return self.inflight is not None or bool((self.game_id >= 0).any())
@@ -270,6 +331,7 @@ class _Lane:
                         reset[s] = 1
                 if reset.any():
                     eng.reset(torch.from_numpy(reset))
+                    self._open_games(np.nonzero(reset)[0])
         self.step_no += 1
 
     def _pack_planes(self, planes):

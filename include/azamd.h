@@ -186,6 +186,17 @@ int az_rng_dirichlet(az_rng* r, const int32_t* counts_host, double alpha, double
 /* One uniform double in [0,1) per stream with mask_host[g] != 0 (NULL = all): RandomState.random_sample(). */
 int az_rng_random_sample(az_rng* r, const uint8_t* mask_host, double* out_host);
 
+/* ---- replay batch assembly (go_zero/train.py:147-176 ReplayBuffer.sample, :187-207 symmetries) ----
+ * Gathers `count` sampled positions idx[i] from a device-resident replay store and applies dihedral
+ * symmetry sym[i] (0..7, the numbering of train.py:187-192) to planes and policy. Store layout: `bits`
+ * [capacity][row_bytes] = the 2H+3 binary planes of to_tensor() packed row-major, most significant bit
+ * first; `caps` [capacity][2] = the two capture planes' values; `pi` [capacity][A]. `perm` [8][n*n]:
+ * source point of every destination point under each symmetry. Outputs float32 [count][2H+5][n][n] and
+ * [count][A], exactly what ReplayBuffer.sample stacks on the host. */
+int az_replay_gather(const uint8_t* bits, const float* caps, const float* pi, const int16_t* perm, const int32_t* idx,
+                     const int32_t* sym, int32_t count, int32_t board_size, int32_t history_len, int32_t row_bytes,
+                     float* out_states, float* out_pi, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,121 @@
+"""Training-side callers on the GPU against the upstream vectors of tests/golden/train.*: arena matches,
+lockstep self-play vs one-game upstream workers, the opening book, device batch assembly, the main loop."""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+import golden_io
+from test_train_cpu import J, Z, synth_samples, tiny_cfg, tiny_model
+
+pytestmark = pytest.mark.gpu
+
+
+def test_play_match_and_sprt_match_upstream():
+    from alphazero_amd import train as T
+    cfg = tiny_cfg()
+    ma, mb = tiny_model(cfg, J["tiny_seeds"]["arena"][0]), tiny_model(cfg, J["tiny_seeds"]["arena"][1])
+    assert list(T.play_match(ma, mb, cfg, 5)) == J["play_match"]
+    for th, want in zip((0.55, 0.3, 0.9), J["play_match_sprt"]):
+        assert list(T.play_match_sprt(ma, mb, cfg, 12, th, 0.05)) == want
+    assert T.play_match(ma, mb, cfg, 0) == (0, 0, 0)
+
+
+def test_arena_games_are_functions_of_the_colour_assignment():
+    """What lets play_match play two games instead of `games`: a repeated game ends the same way."""
+    from alphazero_amd import train as T
+    cfg = tiny_cfg()
+    ma, mb = tiny_model(cfg, 5), tiny_model(cfg, 6)
+    out = T._arena_results(ma, mb, cfg, [True, False, True, False, False])
+    assert out[0] == out[2] and out[1] == out[3] == out[4]
+
+
+def test_run_selfplay_reproduces_one_game_upstream_workers():
+    """Game j of an iteration equals what an upstream worker seeded seed + iter*1000 + j plays (train.py:446)."""
+    from alphazero_amd import train as T
+    cfg = tiny_cfg(mcts_topk_expand=6, seed=9, selfplay_games_per_iter=3)
+    model = tiny_model(cfg, J["tiny_seeds"]["selfplay"])
+    samples, bw, ww, dd = T.run_selfplay(model, cfg, iter_idx=2)
+    want = J["selfplay_workers"]
+    assert (bw, ww, dd) == tuple(sum(w[i] for w in want) for i in range(3))
+    assert len(samples) == sum(w[3] for w in want)
+    off = 0
+    for wid, w in enumerate(want):
+        mine = samples[off:off + w[3]]
+        off += w[3]
+        planes = np.packbits(np.stack([s[0][:19] for s in mine]) > 0.5)
+        assert np.array_equal(planes, Z[f"worker{wid}/states"])
+        assert np.array_equal(np.stack([s[0][19:, 0, 0] for s in mine]), Z[f"worker{wid}/caps"])
+        assert np.stack([s[1] for s in mine]).tobytes() == Z[f"worker{wid}/pi"].tobytes()
+        assert np.array_equal(np.array([s[2] for s in mine]), Z[f"worker{wid}/z"])
+        assert np.array_equal(np.array([s[3] for s in mine]), Z[f"worker{wid}/difficulty"])
+
+
+def test_selfplay_game_with_opening_book():
+    from alphazero_amd import train as T
+    cfg = tiny_cfg(opening_book_prob=1.0, opening_book_max_moves=3, seed=4)
+    model = tiny_model(cfg, J["tiny_seeds"]["selfplay"])
+    T.set_seed(1234)
+    data, winner = T.selfplay_game(model, cfg)
+    assert winner == J["book_game"]["winner"] and len(data) == J["book_game"]["moves"]
+    assert np.stack([s[1] for s in data]).tobytes() == Z["book_game/pi"].tobytes()
+    assert np.array_equal(data[0][0], Z["book_game/first_planes"])
+    # the lockstep driver opens game 0 with the same book line when it is seeded like that run
+    from alphazero_amd.selfplay import BatchedSelfPlay, SelfPlayConfig
+    sp = BatchedSelfPlay(T._host_evaluator(model), SelfPlayConfig.from_train_config(cfg), games=2, seed0=1234)
+    sp.begin(num_games=2)
+    board = sp.eng.export_state()[0].cpu().numpy()[0, :25]
+    first = Z["book_game/first_planes"]
+    want = np.where(first[0] > 0.5, -1, 0) + np.where(first[8] > 0.5, 1, 0)     # three book stones: white to play sees black as "theirs"
+    assert np.array_equal(board.reshape(5, 5), want.astype(np.int8))
+    assert sp.lanes[0].move_idx[0] == 3
+
+
+def test_device_batch_assembly_equals_host_sampling():
+    from alphazero_amd import train as T
+    buf = T.ReplayBuffer(capacity=50)
+    buf.extend(synth_samples(30, 5, 8, seed=11))
+    buf.attach_device("cuda", 5, 8)
+    buf.extend(synth_samples(70, 5, 8, seed=11)[30:])          # wraps around the ring
+    for aug in (False, True):
+        random.seed(5); np.random.seed(6)
+        hs, hp, hv = buf.sample(16, 5, aug)
+        random.seed(5); np.random.seed(6)
+        ds, dp, dv = buf.sample_device(16, 5, aug)
+        assert ds.is_cuda and torch.equal(ds.cpu(), hs) and torch.equal(dp.cpu(), hp) and torch.equal(dv.cpu(), hv)
+    random.seed(100 + 1); np.random.seed(200 + 1)
+    ds, dp, dv = buf.sample_device(16, 5, True)
+    assert np.array_equal(ds.cpu().numpy(), Z["replay/states_1"]) and np.array_equal(dp.cpu().numpy(), Z["replay/policies_1"])
+    with pytest.raises(ValueError):
+        bad = T.ReplayBuffer(4)
+        bad.extend([(np.full((21, 5, 5), 0.5, np.float32), np.zeros(26, np.float32), 0.0, 0.1)])
+        bad.attach_device("cuda", 5, 8)
+
+
+def test_training_loop_writes_upstream_files(tmp_path, capsys):
+    from alphazero_amd import train as T
+    save = str(tmp_path / "ck")
+    cfg = T.parse_args(["--device", "cuda", "--board-size", "5", "--channels", "32", "--num-blocks", "1", "--value-hidden-dim", "64",
+                        "--iterations", "2", "--selfplay-games-per-iter", "6", "--mcts-simulations", "8", "--eval-simulations", "8",
+                        "--mcts-inference-batch", "4", "--batch-size", "32", "--train-steps-per-iter", "3", "--arena-games", "4",
+                        "--elo-games-per-opponent", "2", "--benchmark-games-per-opponent", "2", "--save-dir", save, "--seed", "3"])
+    assert cfg.use_amp
+    T.run_training(cfg)
+    out = capsys.readouterr().out
+    assert "[Iter 1]" in out and "[Iter 2]" in out
+    names = set(os.listdir(save))
+    assert {"iter_001.pt", "iter_002.pt", "model_pool.json", "model_pool", "_runtime_best_v000000.pt"} <= names
+    ck = torch.load(os.path.join(save, "iter_002.pt"), map_location="cpu", weights_only=True)
+    assert {"iter", "model", "best_model", "candidate_model", "cfg", "buffer_size", "promoted", "arena", "pool_best"} <= set(ck)
+    assert ck["iter"] == 2 and set(ck["arena"]) == {"wins", "losses", "draws"} and set(J["defaults"]) <= set(ck["cfg"])
+    pool = json.load(open(os.path.join(save, "model_pool.json")))
+    assert pool["best_name"] in pool["entries"] and os.path.exists(pool["entries"][pool["best_name"]]["path"])
+    # a checkpoint resumes, and its network loads into the model class under the upstream keys
+    cfg2 = T.parse_args(["--device", "cuda", "--board-size", "5", "--channels", "32", "--num-blocks", "1", "--value-hidden-dim", "64",
+                         "--iterations", "2", "--resume", os.path.join(save, "iter_002.pt"), "--save-dir", save])
+    T.run_training(cfg2)           # nothing left to do: start_iter = 3 > iterations
+    m, c = T.load_model_from_file(os.path.join(save, "model_pool", "model_iter_000.pt"), "cpu")
+    assert c["board_size"] == 5 and m.board_size == 5
