@@ -376,6 +376,12 @@ def _world():
     return None, 0, 1
 
 
+def rank_share(games: int, rank: int, world: int):
+    """(first game id, game count) of `rank` when `games` games are dealt to `world` ranks in contiguous blocks."""
+    first = rank * games // world
+    return first, (rank + 1) * games // world - first
+
+
 def run_selfplay(best_model, cfg, iter_idx: int, pool=None, model_path=None, model_version: int = 0):
     """train.py:395-463 on the GPU: returns (samples, black_wins, white_wins, draws) for this rank's share of
     cfg.selfplay_games_per_iter games (all of them without torch.distributed). `pool`, `model_path` and
@@ -383,9 +389,7 @@ def run_selfplay(best_model, cfg, iter_idx: int, pool=None, model_path=None, mod
     del pool, model_path, model_version
     from .selfplay import BatchedSelfPlay, SelfPlayConfig
     _, rank, world = _world()
-    games = cfg.selfplay_games_per_iter
-    first = rank * games // world
-    mine = (rank + 1) * games // world - first
+    first, mine = rank_share(cfg.selfplay_games_per_iter, rank, world)
     if mine <= 0:
         return [], 0, 0, 0
     best_model.eval()
@@ -784,7 +788,23 @@ def run_training(cfg):
 
 
 def main(argv=None):
-    run_training(parse_args(argv))
+    """go_zero.train.main. Under `python -m torch.distributed.run --nproc-per-node N` (RANK / WORLD_SIZE /
+    LOCAL_RANK in the environment) with a cuda device, each process takes GPU LOCAL_RANK and joins an RCCL group."""
+    cfg = parse_args(argv)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and str(cfg.device).startswith("cuda"):
+        import torch.distributed as dist
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        cfg.device = f"cuda:{local}"
+        if not dist.is_initialized():
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        try:
+            run_training(cfg)
+        finally:
+            dist.destroy_process_group()
+    else:
+        run_training(cfg)
 
 
 if __name__ == "__main__":

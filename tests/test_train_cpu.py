@@ -183,3 +183,12 @@ def test_go_zero_train_surface():
     for name in ("run_selfplay", "selfplay_game", "train_candidate", "play_match", "play_match_sprt", "run_training",
                  "create_mcts", "build_model", "filter_selfplay_samples", "apply_symmetry_to_tensor", "set_seed"):
         assert callable(getattr(G, name)), name
+
+
+def test_rank_share_covers_every_game_once():
+    for games in (0, 1, 7, 40, 4096):
+        for world in (1, 2, 3, 8):
+            parts = [T.rank_share(games, r, world) for r in range(world)]
+            assert parts[0][0] == 0 and sum(c for _, c in parts) == games
+            assert all(parts[r][0] + parts[r][1] == parts[r + 1][0] for r in range(world - 1))
+            assert max(c for _, c in parts) - min(c for _, c in parts) <= 1
