@@ -135,6 +135,8 @@ def main():
     sp = BatchedSelfPlay(net, cfg, games=a.games, seed0=1 + rank * a.games, dedup_leaves=not a.no_dedup, lanes=a.lanes,
                          tower_workgroups=twg)
     sp.begin(num_games=10 ** 9)          # slots refill for as long as the run lasts
+    for _ in range(2):                   # set-up, before the W warm-up steps: first-use allocations (head-activation scratch
+        sp.step()                        # for the largest batch, torch's allocator pools) and filling the lane pipeline
     for _ in range(a.warmup):
         sp.step()
 
