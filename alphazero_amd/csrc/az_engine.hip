@@ -428,6 +428,7 @@ __global__ __launch_bounds__(64) void k_select(Dev d, int batch_n) {
     __shared__ int8_t root_col[BoardLds<PPL>::NPAD];
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
     uint64_t* seen_lds = (uint64_t*)dyn;
+    int* path_lds = (int*)(seen_lds + d.seen_cap);   // the current descent's nodes
     const int g = blockIdx.x, lane = threadIdx.x;
     if (!d.active[g]) { if (lane == 0) d.n_unique[g] = 0; return; }
     Geo<PPL> geo;
@@ -444,19 +445,18 @@ __global__ __launch_bounds__(64) void k_select(Dev d, int batch_n) {
     const int16_t* action = d.action + nb; const int* child_off = d.child_off + nb; const int16_t* n_child = d.n_child + nb;
     int n_unique = 0, depth_sum = 0, max_depth = 0, n_term = 0;
 
+    // The descent itself needs no board: children only exist for legal moves, and whether a node is terminal
+    // follows from the pass count and the move count (go.py:205-206). The moves are replayed on the LDS board
+    // only for a terminal leaf, whose outcome needs the final position (the leaf gather replays the others).
     for (int slot = 0; slot < batch_n; ++slot) {
-        Sim<PPL> s = root;
-#pragma unroll
-        for (int k = 0; k < PPL; ++k)
-            if (geo.p[k] >= 0) b.col[geo.p[k]] = root_col[geo.p[k]];
-        __syncthreads();
         int* path = d.path + ((size_t)g * d.B + slot) * d.max_depth;
         int node = 0, len = 1;
-        if (lane == 0) path[0] = 0;
+        int passes = root.passes, moves = root.moves;
+        if (lane == 0) path_lds[0] = 0;
         bool failed = false;
         while (true) {
             const int nc = n_child[node];
-            if (nc == 0 || sim_terminal<PPL>(d, s) || len >= d.max_depth) break;
+            if (nc == 0 || passes >= 2 || moves >= 2 * d.np || len >= d.max_depth) break;
             // mcts.py:97-116
             const int first = child_off[node];
             int pv = visits[node];
@@ -478,14 +478,26 @@ __global__ __launch_bounds__(64) void k_select(Dev d, int batch_n) {
             wave_argmax(best, best_i);
             if (best_i == 0x7fffffff) { failed = true; break; }  // mcts.py:114-115
             node = first + best_i;
-            sim_play<PPL>(d, lane, geo, b, seen_lds, nullptr, s, (int)action[node]);
-            if (lane == 0) path[len] = node;
+            passes = (int)action[node] == d.np ? passes + 1 : 0;
+            moves += 1;
+            if (lane == 0) path_lds[len] = node;
             len += 1;
         }
         if (failed) { if (lane == 0) atomicMin(&d.ctl[1], (int)AZ_ERR_NOCHILD); }
+        __syncthreads();
+        for (int i = lane; i < len; i += 64) path[i] = path_lds[i];
+        const bool terminal = passes >= 2 || moves >= 2 * d.np;
+        Sim<PPL> s = root;
+        if (terminal) {
+#pragma unroll
+            for (int k = 0; k < PPL; ++k)
+                if (geo.p[k] >= 0) b.col[geo.p[k]] = root_col[geo.p[k]];
+            __syncthreads();
+            for (int i = 1; i < len; ++i) sim_play<PPL>(d, lane, geo, b, seen_lds, nullptr, s, (int)action[path_lds[i]]);
+        }
         const int gs = g * d.B + slot;
         int ref;
-        if (sim_terminal<PPL>(d, s)) {  // mcts.py:191-192
+        if (terminal) {  // mcts.py:191-192
             const double v = sim_outcome<PPL>(d, geo, b, s);
             if (lane == 0) d.term_value[gs] = v;
             ref = -1;
@@ -510,7 +522,7 @@ __global__ __launch_bounds__(64) void k_select(Dev d, int batch_n) {
         __syncthreads();
         if (d.vl > 0.0) {  // mcts.py:196-199
             for (int i = lane; i < len; i += 64) {
-                const int pn = path[i];
+                const int pn = path_lds[i];
                 visits[pn] += 1;
                 vsum[pn] -= d.vl;
             }
@@ -991,7 +1003,7 @@ int az_mcts_select(az_engine* e, void* stream) {
     if (!e) return fail(AZ_ERR_ARG, "null engine");
     if (e->phase != PH_NEED_SELECT) return fail(AZ_ERR_STATE, "az_mcts_select: no batch to select (expand the pending rows first)");
     e->batch_n = std::min(e->d.B, e->d.sims - e->sims_done);
-    DISPATCH_PPL(e, k_select, e->d.G, seen_bytes(e), stream, e->d, e->batch_n);
+    DISPATCH_PPL(e, k_select, e->d.G, seen_bytes(e) + (size_t)e->d.max_depth * 4, stream, e->d, e->batch_n);
     hipLaunchKernelGGL(k_scan_rows, dim3(1), dim3(1024), 0, (hipStream_t)stream, e->d, 0);
     e->phase = PH_SELECTED;
     e->rows_known = false;
