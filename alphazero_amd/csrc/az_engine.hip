@@ -66,7 +66,8 @@ struct Dev {
     int* row_game; int* row_slot;  // [max_rows]
     uint8_t* row_legal;  // [max_rows][A]
     int* ctl;         // [4] n_rows, error code, -, -
-    long long* stats; // [8]
+    long long* stats; // [8], filled by k_reduce_stats
+    long long* gstats; // [G][8] per-game counters of the current search (no cross-workgroup atomics on the hot kernels)
 };
 
 __device__ inline int sc_idx(int g, int f) { return g * 8 + f; }
@@ -366,11 +367,9 @@ __global__ void k_import(Dev d, const int8_t* board, const int8_t* hist, const i
 // Search kernels
 __global__ __launch_bounds__(64) void k_begin(Dev d, const uint8_t* enable) {
     const int g = blockIdx.x * 64 + threadIdx.x;
-    if (g == 0) {
-        for (int i = 0; i < 8; ++i) d.stats[i] = 0;
-        d.ctl[1] = 0;
-    }
+    if (g == 0) d.ctl[1] = 0;
     if (g >= d.G) return;
+    for (int i = 0; i < 8; ++i) d.gstats[(size_t)g * 8 + i] = 0;
     const int* sc = d.sc + g * 8;
     const bool terminal = sc[SC_PASSES] >= 2 || sc[SC_MOVES] >= 2 * d.np;
     const bool act = !terminal && (!enable || enable[g]);
@@ -429,6 +428,7 @@ __global__ __launch_bounds__(64) void k_select(Dev d, int batch_n) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
     uint64_t* seen_lds = (uint64_t*)dyn;
     int* path_lds = (int*)(seen_lds + d.seen_cap);   // the current descent's nodes
+    int* uniq_lds = path_lds + d.max_depth;          // (slot, leaf node) of the batch's distinct leaves so far
     const int g = blockIdx.x, lane = threadIdx.x;
     if (!d.active[g]) { if (lane == 0) d.n_unique[g] = 0; return; }
     Geo<PPL> geo;
@@ -448,18 +448,29 @@ __global__ __launch_bounds__(64) void k_select(Dev d, int batch_n) {
     // The descent itself needs no board: children only exist for legal moves, and whether a node is terminal
     // follows from the pass count and the move count (go.py:205-206). The moves are replayed on the LDS board
     // only for a terminal leaf, whose outcome needs the final position (the leaf gather replays the others).
+    // The statistics of the root and of its children (lane i: child i, when there are at most 64) live in
+    // registers for the whole batch: every descent starts there, and with virtual loss most end there.
+    const int rnc = n_child[0], rfirst = child_off[0];
+    const bool cached = rnc > 0 && rnc <= 64;
+    double c_prior = 0.0, c_vsum = 0.0, r_vsum = vsum[0];
+    int c_vis = 0, c_nch = 0, c_act = 0, r_vis = visits[0];
+    if (cached && lane < rnc) {
+        c_prior = prior[rfirst + lane]; c_vsum = vsum[rfirst + lane]; c_vis = visits[rfirst + lane];
+        c_nch = n_child[rfirst + lane]; c_act = action[rfirst + lane];
+    }
     for (int slot = 0; slot < batch_n; ++slot) {
         int* path = d.path + ((size_t)g * d.B + slot) * d.max_depth;
-        int node = 0, len = 1;
+        int node = 0, len = 1, nc = rnc;
+        int child_vis = -1;   // visit count of the current node when it is a root child held in registers
         int passes = root.passes, moves = root.moves;
         if (lane == 0) path_lds[0] = 0;
         bool failed = false;
         while (true) {
-            const int nc = n_child[node];
             if (nc == 0 || passes >= 2 || moves >= 2 * d.np || len >= d.max_depth) break;
             // mcts.py:97-116
-            const int first = child_off[node];
-            int pv = visits[node];
+            const bool at_root = cached && node == 0;
+            const int first = at_root ? rfirst : child_off[node];
+            int pv = at_root ? r_vis : (child_vis >= 0 ? child_vis : visits[node]);
             pv = pv < d.tab_len ? pv : d.tab_len - 1;
             const double pbc = d.pbc[pv], sq = d.sqn[pv];
             double best = -INFINITY;
@@ -467,10 +478,10 @@ __global__ __launch_bounds__(64) void k_select(Dev d, int batch_n) {
             for (int i0 = 0; i0 < nc; i0 += 64) {
                 const int i = i0 + lane;
                 if (i < nc) {
-                    const int vc = visits[first + i];
+                    const int vc = at_root ? c_vis : visits[first + i];
                     double pb = pbc * (sq / ((double)vc + 1.0));
-                    const double prior_score = pb * prior[first + i];
-                    const double value_score = -(vc == 0 ? 0.0 : vsum[first + i] / (double)vc);
+                    const double prior_score = pb * (at_root ? c_prior : prior[first + i]);
+                    const double value_score = -(vc == 0 ? 0.0 : (at_root ? c_vsum : vsum[first + i]) / (double)vc);
                     const double score = prior_score + value_score;
                     if (score > -1e18 && (score > best)) { best = score; best_i = i; }
                 }
@@ -478,7 +489,10 @@ __global__ __launch_bounds__(64) void k_select(Dev d, int batch_n) {
             wave_argmax(best, best_i);
             if (best_i == 0x7fffffff) { failed = true; break; }  // mcts.py:114-115
             node = first + best_i;
-            passes = (int)action[node] == d.np ? passes + 1 : 0;
+            const int act = at_root ? __shfl(c_act, best_i) : (int)action[node];
+            nc = at_root ? __shfl(c_nch, best_i) : (int)n_child[node];
+            child_vis = at_root ? __shfl(c_vis, best_i) : -1;
+            passes = act == d.np ? passes + 1 : 0;
             moves += 1;
             if (lane == 0) path_lds[len] = node;
             len += 1;
@@ -505,14 +519,15 @@ __global__ __launch_bounds__(64) void k_select(Dev d, int batch_n) {
         } else {
             ref = slot;
             if (d.dedup) {
-                for (int u = 0; u < n_unique; ++u) {
-                    const int us = d.uniq_slot[g * d.B + u];
-                    const int* up = d.path + ((size_t)g * d.B + us) * d.max_depth;
-                    if (up[d.path_len[g * d.B + us] - 1] == node) { ref = us; break; }
-                }
+                for (int u = 0; u < n_unique; ++u)
+                    if (uniq_lds[2 * u + 1] == node) { ref = uniq_lds[2 * u]; break; }
             }
             if (ref == slot) {
-                if (lane == 0) d.uniq_slot[g * d.B + n_unique] = slot;
+                if (lane == 0) {
+                    d.uniq_slot[g * d.B + n_unique] = slot;
+                    uniq_lds[2 * n_unique] = slot;
+                    uniq_lds[2 * n_unique + 1] = node;
+                }
                 n_unique += 1;
             }
         }
@@ -521,7 +536,12 @@ __global__ __launch_bounds__(64) void k_select(Dev d, int batch_n) {
         max_depth = max(max_depth, len - 1);
         __syncthreads();
         if (d.vl > 0.0) {  // mcts.py:196-199
-            for (int i = lane; i < len; i += 64) {
+            if (cached) {
+                r_vis += 1;
+                r_vsum -= d.vl;
+                if (len > 1 && lane == path_lds[1] - rfirst) { c_vis += 1; c_vsum -= d.vl; }
+            }
+            for (int i = (cached ? 2 : 0) + lane; i < len; i += 64) {
                 const int pn = path_lds[i];
                 visits[pn] += 1;
                 vsum[pn] -= d.vl;
@@ -530,15 +550,19 @@ __global__ __launch_bounds__(64) void k_select(Dev d, int batch_n) {
         __threadfence_block();
         __syncthreads();
     }
+    if (cached) {
+        if (lane < rnc) { visits[rfirst + lane] = c_vis; vsum[rfirst + lane] = c_vsum; }
+        if (lane == 0) { visits[0] = r_vis; vsum[0] = r_vsum; }
+    }
     if (lane == 0) {
         d.n_unique[g] = n_unique;
-        atomicAdd((unsigned long long*)&d.stats[ST_DEPTH_SUM], (unsigned long long)depth_sum);
-        atomicMax((unsigned long long*)&d.stats[ST_MAX_DEPTH], (unsigned long long)max_depth);
-        atomicAdd((unsigned long long*)&d.stats[ST_TERMINAL], (unsigned long long)n_term);
-        atomicAdd((unsigned long long*)&d.stats[ST_SIMS], (unsigned long long)batch_n);
-        int raw = batch_n - n_term;
-        atomicAdd((unsigned long long*)&d.stats[ST_ROWS_RAW], (unsigned long long)raw);
-        atomicAdd((unsigned long long*)&d.stats[ST_ROWS], (unsigned long long)n_unique);
+        long long* gs = d.gstats + (size_t)g * 8;
+        gs[ST_DEPTH_SUM] += depth_sum;
+        gs[ST_MAX_DEPTH] = max(gs[ST_MAX_DEPTH], (long long)max_depth);
+        gs[ST_TERMINAL] += n_term;
+        gs[ST_SIMS] += batch_n;
+        gs[ST_ROWS_RAW] += batch_n - n_term;
+        gs[ST_ROWS] += n_unique;
     }
 }
 
@@ -715,7 +739,7 @@ __device__ inline void expand_node(const Dev& d, int g, int lane, int node, cons
     if (!already && lane == 0) {
         d.child_off[nbase + node] = first;
         d.n_child[nbase + node] = (int16_t)cnt;
-        atomicMax((unsigned long long*)&d.stats[ST_MAX_NODES], (unsigned long long)(first + cnt));
+        d.gstats[(size_t)g * 8 + ST_MAX_NODES] = max(d.gstats[(size_t)g * 8 + ST_MAX_NODES], (long long)(first + cnt));
     }
     __threadfence_block();
     __syncthreads();
@@ -796,6 +820,24 @@ __global__ __launch_bounds__(64) void k_result(Dev d, int* visits_out, double* r
     const int first = d.child_off[nb], nc = d.n_child[nb];
     for (int i = lane; i < nc; i += 64) visits_out[(size_t)g * d.A + d.action[nb + first + i]] = d.visits[nb + first + i];
     if (lane == 0) root_value[g] = d.visits[nb] == 0 ? 0.0 : d.vsum[nb] / (double)d.visits[nb];  // mcts.py:24-27
+}
+
+// Sum (or maximum, for the two high-water marks) of the per-game counters.
+__global__ __launch_bounds__(256) void k_reduce_stats(Dev d) {
+    __shared__ long long part[256][8];
+    long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int g = threadIdx.x; g < d.G; g += 256) {
+        const long long* gs = d.gstats + (size_t)g * 8;
+        for (int i = 0; i < 8; ++i) acc[i] = (i == ST_MAX_DEPTH || i == ST_MAX_NODES) ? max(acc[i], gs[i]) : acc[i] + gs[i];
+    }
+    for (int i = 0; i < 8; ++i) part[threadIdx.x][i] = acc[i];
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        const int i = threadIdx.x;
+        long long r = 0;
+        for (int t = 0; t < 256; ++t) r = (i == ST_MAX_DEPTH || i == ST_MAX_NODES) ? max(r, part[t][i]) : r + part[t][i];
+        d.stats[i] = r;
+    }
 }
 
 }  // namespace az
@@ -883,7 +925,7 @@ int az_engine_create(const az_config* c, az_engine** out) {
     ALLOC(path, (size_t)d.G * d.B * d.max_depth); ALLOC(path_len, (size_t)d.G * d.B); ALLOC(leaf_ref, (size_t)d.G * d.B);
     ALLOC(term_value, (size_t)d.G * d.B); ALLOC(n_unique, d.G); ALLOC(uniq_slot, (size_t)d.G * d.B);
     ALLOC(row_off, d.G + 1); ALLOC(row_game, d.max_rows); ALLOC(row_slot, d.max_rows);
-    ALLOC(row_legal, (size_t)d.max_rows * d.A); ALLOC(ctl, 4); ALLOC(stats, 8);
+    ALLOC(row_legal, (size_t)d.max_rows * d.A); ALLOC(ctl, 4); ALLOC(stats, 8); ALLOC(gstats, (size_t)d.G * 8);
     {
         int rc = dev_alloc(e, &e->last_priors, (size_t)d.max_rows * d.A);
         if (rc != AZ_OK) { az_engine_destroy(e); return rc; }
@@ -912,6 +954,7 @@ int az_engine_create(const az_config* c, az_engine** out) {
     }
     HIP_TRY(hipMemset(d.ctl, 0, 4 * sizeof(int)));
     HIP_TRY(hipMemset(d.stats, 0, 8 * sizeof(long long)));
+    HIP_TRY(hipMemset(d.gstats, 0, (size_t)d.G * 8 * sizeof(long long)));
     *out = e;
     int rc = az_rules_reset(e, nullptr, nullptr);
     if (rc != AZ_OK) { az_engine_destroy(e); *out = nullptr; return rc; }
@@ -1003,7 +1046,7 @@ int az_mcts_select(az_engine* e, void* stream) {
     if (!e) return fail(AZ_ERR_ARG, "null engine");
     if (e->phase != PH_NEED_SELECT) return fail(AZ_ERR_STATE, "az_mcts_select: no batch to select (expand the pending rows first)");
     e->batch_n = std::min(e->d.B, e->d.sims - e->sims_done);
-    DISPATCH_PPL(e, k_select, e->d.G, seen_bytes(e) + (size_t)e->d.max_depth * 4, stream, e->d, e->batch_n);
+    DISPATCH_PPL(e, k_select, e->d.G, seen_bytes(e) + ((size_t)e->d.max_depth + 2 * (size_t)e->d.B) * 4, stream, e->d, e->batch_n);
     hipLaunchKernelGGL(k_scan_rows, dim3(1), dim3(1024), 0, (hipStream_t)stream, e->d, 0);
     e->phase = PH_SELECTED;
     e->rows_known = false;
@@ -1116,6 +1159,7 @@ int az_mcts_last_priors(az_engine* e, double* priors, void* stream) {
 
 int az_mcts_stats(az_engine* e, int64_t* out, void* stream) {
     if (!e || !out) return fail(AZ_ERR_ARG, "null argument");
+    hipLaunchKernelGGL(k_reduce_stats, dim3(1), dim3(256), 0, (hipStream_t)stream, e->d);
     HIP_TRY(hipMemcpyAsync(e->stats_host, e->d.stats, 8 * sizeof(long long), hipMemcpyDeviceToHost, (hipStream_t)stream));
     if (e->async_mode) HIP_TRY(hipMemcpyAsync(e->ctl_host, e->d.ctl, 4 * sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
