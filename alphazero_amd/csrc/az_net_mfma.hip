@@ -320,7 +320,7 @@ __device__ __forceinline__ void gemm_conv(f32x4 (&acc)[MI][NI], const uint4* __r
         vmask[mi] = m;
         roff[mi] = row * in_stride + kq * 16;
     }
-    const int zoff = (int)(zrow - act) + kq * 16;
+    const int zbase = (int)(zrow - act);
     const int woff = ((wn * NI) * 64 + lane) * 16;   // this wave's first channel tile inside a k-step image
     const int soff = (wave * 64 + lane) * 16;        // where this lane's staged vector of piece `wave` goes
     int apc[MI], apn[MI];                            // fragment offsets of the current / next tap (channel offset 0)
@@ -329,7 +329,12 @@ __device__ __forceinline__ void gemm_conv(f32x4 (&acc)[MI][NI], const uint4* __r
         const int shift = (dy * g.n + dx) * in_stride;
         const int bit = tap < ntaps ? 1 << tap : 0;
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) out[mi] = (vmask[mi] & bit) ? roff[mi] + shift : zoff;
+        for (int mi = 0; mi < MI; ++mi) {
+            // A lane whose tap leaves the board reads zeros from the spot of the zero region that has the banks of
+            // the address it would have read (the region is 256-byte aligned), so the redirection adds no conflict.
+            const int reg = roff[mi] + shift;
+            out[mi] = (vmask[mi] & bit) ? reg : zbase + (reg & 255);
+        }
     };
     tap_offsets(apc, 0);
     // tiles 0 and 1 have landed; the PW register fetches issued after them may still fly (the counter retires in order)
@@ -601,8 +606,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_tower(TowerPara
     static_assert(NI % 2 == 0 && NIH % 2 == 0, "channel tiles are stored in pairs");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* act = smem;
-    char* zrow = smem + 256 * STRIDE;
-    char* bbuf = zrow + ((STRIDE + 127) / 128) * 128;
+    constexpr int ZBYTES = ((256 + 2 * C + 16 + 127) / 128) * 128;   // zero region, see gemm_conv
+    char* zrow = smem + ((256 * STRIDE + 255) / 256) * 256;
+    char* bbuf = zrow + ZBYTES;
     float* scratch = (float*)bbuf;  // epilogue scratch shares the weight staging buffers
     const int tid = threadIdx.x;
     uint4* xres_wg = P.xres + (size_t)blockIdx.x * NV * NT;
@@ -610,7 +616,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_tower(TowerPara
     unsigned long long stamp_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_last;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
 #endif
-    for (int i = tid; i < STRIDE / 4; i += NT) ((uint32_t*)zrow)[i] = 0;
+    for (int i = tid; i < ZBYTES / 4; i += NT) ((uint32_t*)zrow)[i] = 0;
     TileGeo g;
     g.n = P.n; g.np = P.np; g.recip_np = P.recip_np; g.recip_n = P.recip_n;
     const int rows = P.rows_dev ? min(*P.rows_dev, P.rows) : P.rows;
@@ -991,7 +997,8 @@ static size_t tower_lds_bytes(int C, int NH, int TB, int hid) {
     const size_t stride = 2 * C + 32;
     const size_t tile = (size_t)64 * std::max(C, NH) * 2;
     const size_t se = ((size_t)2 * TB * C + (size_t)TB * hid) * 4 + 16 + se_blob_bytes(C, hid);
-    return 256 * stride + ((stride + 127) / 128) * 128 + std::max(2 * tile, se);
+    const size_t zbytes = ((256 + 2 * (size_t)C + 16 + 127) / 128) * 128;
+    return ((256 * stride + 255) / 256) * 256 + zbytes + std::max(2 * tile, se);
 }
 
 int mfma_create(const az_net_config& c, const NetLayout& L, const float* Pm, MfmaNet** out) {
