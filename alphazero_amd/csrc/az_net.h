@@ -24,9 +24,18 @@ void net_layout(const az_net_config& c, NetLayout& L);
 void fold_bn(const float* P, int64_t w_off, const BnOff& bn, int cout, int64_t per_out, std::vector<float>& w,
              std::vector<float>& b);
 
+// bf16 layer-by-layer tower for shapes the fused kernel does not hold in LDS (az_net_layers.hip)
+struct LayerNet;
+bool layers_supported(const az_net_config& c);
+int layers_create(const az_net_config& c, const NetLayout& L, const float* params, LayerNet** out);
+void layers_destroy(LayerNet* m);
+int layers_chunk_boards(const LayerNet* m);
+int layers_tower(LayerNet* m, const uint16_t* feat, int boards, uint16_t* hq, hipStream_t st);
+
 // bf16 MFMA path (az_net_mfma.hip)
 struct MfmaNet;
 bool mfma_supported(const az_net_config& c);
+bool mfma_is_fused(const MfmaNet* m);
 int mfma_create(const az_net_config& c, const NetLayout& L, const float* params, MfmaNet** out);
 void mfma_destroy(MfmaNet* m);
 void mfma_set_profiling(MfmaNet* m, bool on);

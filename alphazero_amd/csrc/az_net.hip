@@ -274,6 +274,12 @@ static int ensure_scratch(az_net* net, int rows) {
     return AZ_OK;
 }
 
+int az_net_is_fused(az_net* net, int32_t* fused) {
+    if (!net || !fused) return fail(AZ_ERR_ARG, "null argument");
+    *fused = (net->cfg.precision == AZ_NET_BF16 && net->mfma && mfma_is_fused(net->mfma)) ? 1 : 0;
+    return AZ_OK;
+}
+
 int az_net_profile_spans(az_net* net, double* spans_ms, int64_t capacity, int64_t* count) {
     if (!net || !count || (capacity > 0 && !spans_ms)) return fail(AZ_ERR_ARG, "null argument");
     if (net->cfg.precision != AZ_NET_BF16 || !net->mfma) return fail(AZ_ERR_STATE, "az_net_profile_spans: bf16 network not loaded");

@@ -1,0 +1,328 @@
+// bf16 MFMA inference of the policy/value tower (model.py:43-97, eval mode) layer by layer, for the shapes
+// whose activations do not fit one workgroup's LDS (boards above 9x9, 256 channels): every 3x3 / 1x1
+// convolution is one launch of k_conv_layer, an implicit GEMM over all boards of a chunk with the same
+// v_mfma_f32_16x16x32_bf16 tile loop as the fused tower (az_mfma_gemm.cuh) -- weight tiles double-buffered in
+// LDS, activation fragments read straight from the bf16 [position][channel] arrays in HBM/L2. The
+// squeeze-excite gate (pooled in position order, so a board's result does not depend on its neighbours in the
+// batch) and the residual add are two small bandwidth-bound kernels between the convolutions.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "az_net.h"
+#include "az_mfma_gemm.cuh"
+
+namespace az {
+int fail(int code, const std::string& msg);
+
+struct ConvArgs {
+    const char* in;        // [rows][in_stride bytes] bf16 activations, followed by a zero region at zero_off
+    int in_stride, zero_off;
+    const uint4* w;        // packed weight tiles, one run of w_block_vecs vectors per block of NCOLS output channels
+    size_t w_block_vecs;
+    const float* bias;     // [cout]
+    char* out;             // [rows][out_stride bytes] bf16
+    int out_stride, rows, n, np, ntaps, relu;
+};
+
+template <int KPT, int NCOLS, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_conv_layer(ConvArgs a) {
+    constexpr int MI = 256 / (WM * 16), NI = NCOLS / (WN * 16);
+    static_assert(NI % 2 == 0, "channel tiles are stored in pairs");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    TileGeo g;
+    g.row0 = blockIdx.x * 256; g.n = a.n; g.np = a.np; g.vrows = a.rows; g.recip_np = 0; g.recip_n = 0;
+    f32x4 acc[MI][NI];
+    zero_acc<MI, NI>(acc);
+    gemm_conv<MI, NI, WM, WN, NCOLS, KPT, true>(acc, a.w + (size_t)blockIdx.y * a.w_block_vecs, a.ntaps, a.ntaps == 9, a.in, a.in_stride,
+                                                  a.in + a.zero_off, smem, g);
+    AZ_LANE_GEO(MI, NI, WN);
+    const int cbase = blockIdx.y * NCOLS + col0 + 8 * kq;
+#pragma unroll
+    for (int p = 0; p < NI / 2; ++p) {
+        const float4 x0 = *(const float4*)(a.bias + cbase + 32 * p), x1 = *(const float4*)(a.bias + cbase + 32 * p + 4);
+        const float bv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int row = g.row0 + row_base + mi * 16 + lr;
+            float v[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { v[r] = acc[mi][2 * p][r] + bv[r]; v[4 + r] = acc[mi][2 * p + 1][r] + bv[4 + r]; }
+            if (a.relu) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
+            if (row < a.rows)
+                *(uint4*)(a.out + (size_t)row * a.out_stride + (size_t)(cbase + 32 * p) * 2) =
+                    make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
+        }
+    }
+}
+
+// [rows][32] bf16 feature rows -> [rows][64] (upper half zero): the stem then runs through the same tile loop.
+__global__ __launch_bounds__(256) void k_pad_features(const uint4* __restrict__ in, uint4* __restrict__ out, int rows) {
+    const int i = blockIdx.x * 256 + threadIdx.x;   // one 16-byte piece of an output row (8 per row)
+    if (i >= rows * 8) return;
+    const int row = i >> 3, part = i & 7;
+    out[i] = part < 4 ? in[row * 4 + part] : make_uint4(0, 0, 0, 0);
+}
+
+// Squeeze-excite gate of every board (model.py:9-22): mean over the board's positions in index order, two small
+// fully connected layers in float32, sigmoid. One workgroup per board.
+__global__ __launch_bounds__(256) void k_se_gate_layer(const uint16_t* __restrict__ y, int np, int C, int hid, const float* __restrict__ w1,
+                                                       const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2,
+                                                       float* __restrict__ gate) {
+    extern __shared__ float sh[];   // pooled [C], hidden [hid]
+    float* pooled = sh;
+    float* hidden = sh + C;
+    const int b = blockIdx.x;
+    const uint16_t* yb = y + (size_t)b * np * C;
+    const float inv = 1.0f / (float)np;
+    for (int ch = threadIdx.x; ch < C; ch += blockDim.x) {
+        float s = 0.f;
+        for (int p = 0; p < np; ++p) s += __uint_as_float((uint32_t)yb[(size_t)p * C + ch] << 16);
+        pooled[ch] = s * inv;
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < hid; j += blockDim.x) {
+        float s = b1[j];
+        for (int ch = 0; ch < C; ++ch) s = fmaf(w1[j * C + ch], pooled[ch], s);
+        hidden[j] = fmaxf(s, 0.f);
+    }
+    __syncthreads();
+    for (int ch = threadIdx.x; ch < C; ch += blockDim.x) {
+        float s = b2[ch];
+        for (int j = 0; j < hid; ++j) s = fmaf(w2[ch * hid + j], hidden[j], s);
+        gate[(size_t)b * C + ch] = 1.f / (1.f + __expf(-s));
+    }
+}
+
+// x <- relu(y * gate + x) (model.py:38-40), 8 channels per thread; gate == nullptr: no squeeze-excite.
+__global__ __launch_bounds__(256) void k_scale_residual(const uint4* __restrict__ y, const float* __restrict__ gate, uint4* __restrict__ x,
+                                                        int rows, int np, int C) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int per_row = C / 8;
+    if (i >= (size_t)rows * per_row) return;
+    const int row = (int)(i / per_row), c8 = (int)(i - (size_t)row * per_row) * 8;
+    const uint4 yv = y[i], xv = x[i];
+    const uint32_t yu[4] = {yv.x, yv.y, yv.z, yv.w}, xu[4] = {xv.x, xv.y, xv.z, xv.w};
+    float gv[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+    if (gate) {
+        const float* gp = gate + (size_t)(row / np) * C + c8;
+        const float4 g0 = *(const float4*)gp, g1 = *(const float4*)(gp + 4);
+        gv[0] = g0.x; gv[1] = g0.y; gv[2] = g0.z; gv[3] = g0.w; gv[4] = g1.x; gv[5] = g1.y; gv[6] = g1.z; gv[7] = g1.w;
+    }
+    uint32_t o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        o[k] = pack_bf16(fmaxf(bf16_lo(yu[k]) * gv[2 * k] + bf16_lo(xu[k]), 0.f), fmaxf(bf16_hi(yu[k]) * gv[2 * k + 1] + bf16_hi(xu[k]), 0.f));
+    x[i] = make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+// ------------------------------------------------------------------------------------------------ host
+struct PackedConv {
+    uint4* w = nullptr;
+    float* b = nullptr;
+    size_t block_vecs = 0;
+    int cin_pad = 0, cout = 0, ncols = 0, taps = 0;
+};
+
+struct LayerNet {
+    az_net_config cfg;
+    int np, q, chunk_boards, ncols;   // ncols: output channels per workgroup of the tower convolutions
+    std::vector<void*> allocs;
+    PackedConv stem, head;
+    std::vector<PackedConv> convs;     // 2 per block
+    std::vector<float*> se;            // per block: w1, b1, w2, b2 (float32), empty without squeeze-excite
+    char *f64 = nullptr, *x = nullptr, *h = nullptr, *y = nullptr;   // chunk activations, each followed by a zero region
+    float* gate = nullptr;
+    size_t zero_off_f = 0, zero_off_c = 0;
+};
+
+static const int kZeroTail = 4096;
+
+template <typename T>
+static int dev_up(LayerNet* m, const T* src, size_t count, T** out) {
+    void* p = nullptr;
+    if (hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess) return fail(AZ_ERR_HIP, "hipMalloc (network weights)");
+    m->allocs.push_back(p);
+    if (count && hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return fail(AZ_ERR_HIP, "hipMemcpy (network weights)");
+    *out = (T*)p;
+    return AZ_OK;
+}
+
+// Folded weights w[cout][cin][taps] -> one packed run per block of `ncols` output channels.
+static int pack_layer(LayerNet* m, const std::vector<float>& w, const std::vector<float>& b, int cout, int cin, int taps, int cin_pad,
+                      int ncols, PackedConv* out) {
+    std::vector<uint16_t> all;
+    size_t block = 0;
+    for (int c0 = 0; c0 < cout; c0 += ncols) {
+        const int nc = std::min(ncols, cout - c0);
+        std::vector<float> sub(w.begin() + (size_t)c0 * cin * taps, w.begin() + (size_t)(c0 + nc) * cin * taps);
+        std::vector<uint16_t> pk = pack_conv(sub, nc, cin, taps, cin_pad, ncols);
+        block = pk.size() * 2 / 16;
+        all.insert(all.end(), pk.begin(), pk.end());
+    }
+    std::vector<float> bias((size_t)((cout + ncols - 1) / ncols) * ncols, 0.f);
+    std::copy(b.begin(), b.end(), bias.begin());
+    uint16_t* wd;
+    int rc = dev_up(m, all.data(), all.size(), &wd);
+    if (rc != AZ_OK) return rc;
+    rc = dev_up(m, bias.data(), bias.size(), &out->b);
+    if (rc != AZ_OK) return rc;
+    out->w = (uint4*)wd; out->block_vecs = block; out->cin_pad = cin_pad; out->cout = cout; out->ncols = ncols; out->taps = taps;
+    return AZ_OK;
+}
+
+bool layers_supported(const az_net_config& c) {
+    const bool cok = c.channels == 64 || c.channels == 128 || c.channels == 192 || c.channels == 256;
+    return cok && c.board_size >= 2 && c.board_size <= 19 && c.in_planes <= 32;
+}
+
+void layers_destroy(LayerNet* m) {
+    if (!m) return;
+    (void)hipSetDevice(m->cfg.device);
+    (void)hipDeviceSynchronize();
+    for (void* p : m->allocs) (void)hipFree(p);
+    delete m;
+}
+
+int layers_chunk_boards(const LayerNet* m) { return m->chunk_boards; }
+
+int layers_create(const az_net_config& c, const NetLayout& L, const float* Pm, LayerNet** out) {
+    if (!layers_supported(c)) return fail(AZ_ERR_ARG, "bf16 layer path: unsupported network shape");
+    if (hipSetDevice(c.device) != hipSuccess) return fail(AZ_ERR_HIP, "hipSetDevice");
+    LayerNet* m = new LayerNet();
+    m->cfg = c;
+    const int C = c.channels, np = c.board_size * c.board_size, q = C / 4;
+    m->np = np; m->q = q;
+    m->ncols = C == 256 ? 128 : C;
+    // boards per chunk: activation arrays of at most ~64 MiB each
+    m->chunk_boards = std::max(16, (int)(((size_t)64 << 20) / ((size_t)np * C * 2)));
+    std::vector<float> w, b;
+    int rc;
+#define TRY(x) if ((rc = (x)) != AZ_OK) { layers_destroy(m); return rc; }
+    fold_bn(Pm, L.stem_w, L.stem_bn, C, (int64_t)c.in_planes * 9, w, b);
+    TRY(pack_layer(m, w, b, C, c.in_planes, 9, 64, m->ncols, &m->stem));
+    for (int i = 0; i < c.blocks; ++i) {
+        const BlockOff& bo = L.blocks[i];
+        PackedConv pc;
+        fold_bn(Pm, bo.conv1, bo.bn1, C, (int64_t)C * 9, w, b);
+        TRY(pack_layer(m, w, b, C, C, 9, C, m->ncols, &pc));
+        m->convs.push_back(pc);
+        fold_bn(Pm, bo.conv2, bo.bn2, C, (int64_t)C * 9, w, b);
+        TRY(pack_layer(m, w, b, C, C, 9, C, m->ncols, &pc));
+        m->convs.push_back(pc);
+        if (c.use_se) {
+            const int hid = c.se_hidden;
+            float* d;
+            TRY(dev_up(m, Pm + bo.se_w1, (size_t)hid * C, &d)); m->se.push_back(d);
+            TRY(dev_up(m, Pm + bo.se_b1, (size_t)hid, &d)); m->se.push_back(d);
+            TRY(dev_up(m, Pm + bo.se_w2, (size_t)C * hid, &d)); m->se.push_back(d);
+            TRY(dev_up(m, Pm + bo.se_b2, (size_t)C, &d)); m->se.push_back(d);
+        }
+    }
+    {   // fused head 1x1: channels [0,q) policy_head.0, [q,2q) value_head.0
+        std::vector<float> wp, bp, wv, bv, wh((size_t)2 * q * C), bh((size_t)2 * q);
+        fold_bn(Pm, L.ph0_w, L.ph0_bn, q, C, wp, bp);
+        fold_bn(Pm, L.vh0_w, L.vh0_bn, q, C, wv, bv);
+        std::copy(wp.begin(), wp.end(), wh.begin());
+        std::copy(wv.begin(), wv.end(), wh.begin() + (size_t)q * C);
+        std::copy(bp.begin(), bp.end(), bh.begin());
+        std::copy(bv.begin(), bv.end(), bh.begin() + q);
+        TRY(pack_layer(m, wh, bh, 2 * q, C, 1, C, 2 * q, &m->head));
+    }
+    const size_t rows = (size_t)m->chunk_boards * np;
+    m->zero_off_f = (rows * 128 + 255) / 256 * 256;
+    m->zero_off_c = (rows * (size_t)C * 2 + 255) / 256 * 256;
+    char** bufs[4] = {&m->f64, &m->x, &m->h, &m->y};
+    for (int i = 0; i < 4; ++i) {
+        const size_t bytes = (i == 0 ? m->zero_off_f : m->zero_off_c) + kZeroTail;
+        void* p = nullptr;
+        if (hipMalloc(&p, bytes) != hipSuccess || hipMemset(p, 0, bytes) != hipSuccess) { layers_destroy(m); return fail(AZ_ERR_HIP, "hipMalloc (layer activations)"); }
+        m->allocs.push_back(p);
+        *bufs[i] = (char*)p;
+    }
+    {
+        void* p = nullptr;
+        if (hipMalloc(&p, (size_t)m->chunk_boards * C * 4) != hipSuccess) { layers_destroy(m); return fail(AZ_ERR_HIP, "hipMalloc (gates)"); }
+        m->allocs.push_back(p);
+        m->gate = (float*)p;
+    }
+#undef TRY
+    *out = m;
+    return AZ_OK;
+}
+
+template <int KPT, int NCOLS, int WM, int WN>
+static void launch_one(const ConvArgs& a, int cout, hipStream_t st) {
+    const dim3 grid((a.rows + 255) / 256, (cout + NCOLS - 1) / NCOLS);
+    hipLaunchKernelGGL((k_conv_layer<KPT, NCOLS, WM, WN>), grid, dim3(64 * WM * WN), (size_t)2 * 64 * NCOLS * 2, st, a);
+}
+
+// Tower convolutions: 4x2 waves of 64 positions x NCOLS/2 channels. Heads: 8x1 waves of 32 positions x all channels.
+static int launch_conv(const PackedConv& pc, const char* in, int zero_off, char* out, int out_stride, int rows, int n, int relu, bool head,
+                       hipStream_t st) {
+    ConvArgs a;
+    a.in = in; a.in_stride = pc.cin_pad * 2; a.zero_off = zero_off; a.w = pc.w; a.w_block_vecs = pc.block_vecs; a.bias = pc.b;
+    a.out = out; a.out_stride = out_stride; a.rows = rows; a.n = n; a.np = n * n; a.ntaps = pc.taps; a.relu = relu;
+    const int key = (pc.cin_pad / 32) * 1000 + pc.ncols;
+    if (!head) {
+        switch (key) {
+            case 2064: launch_one<2, 64, 4, 2>(a, pc.cout, st); break;     // stem or 64-channel tower
+            case 2128: launch_one<2, 128, 4, 2>(a, pc.cout, st); break;    // stem of the 128- and 256-channel towers
+            case 2192: launch_one<2, 192, 4, 2>(a, pc.cout, st); break;    // stem of the 192-channel tower
+            case 4128: launch_one<4, 128, 4, 2>(a, pc.cout, st); break;
+            case 6192: launch_one<6, 192, 4, 2>(a, pc.cout, st); break;
+            case 8128: launch_one<8, 128, 4, 2>(a, pc.cout, st); break;
+            default: return fail(AZ_ERR_ARG, "bf16 layer path: no convolution kernel for this shape");
+        }
+    } else {
+        switch (key) {
+            case 2032: launch_one<2, 32, 8, 1>(a, pc.cout, st); break;
+            case 4064: launch_one<4, 64, 8, 1>(a, pc.cout, st); break;
+            case 6096: launch_one<6, 96, 8, 1>(a, pc.cout, st); break;
+            case 8128: launch_one<8, 128, 8, 1>(a, pc.cout, st); break;
+            default: return fail(AZ_ERR_ARG, "bf16 layer path: no head kernel for this shape");
+        }
+    }
+    return AZ_OK;
+}
+
+// Boards [0, boards) of `feat` ([boards][np][32] bf16) -> hq [boards][np][2q] bf16; boards <= chunk_boards.
+int layers_tower(LayerNet* m, const uint16_t* feat, int boards, uint16_t* hq, hipStream_t st) {
+    const az_net_config& c = m->cfg;
+    const int C = c.channels, n = c.board_size, np = m->np, rows = boards * np;
+    if (boards <= 0) return AZ_OK;
+    if (boards > m->chunk_boards) return fail(AZ_ERR_ARG, "layers_tower: chunk too large");
+    hipLaunchKernelGGL(k_pad_features, dim3((rows * 8 + 255) / 256), dim3(256), 0, st, (const uint4*)feat, (uint4*)m->f64, rows);
+    int rc = launch_conv(m->stem, m->f64, (int)m->zero_off_f, m->x, C * 2, rows, n, 1, false, st);
+    if (rc != AZ_OK) return rc;
+    const int per_row = C / 8;
+    const dim3 egrid((unsigned)(((size_t)rows * per_row + 255) / 256));
+    for (int i = 0; i < c.blocks; ++i) {
+        rc = launch_conv(m->convs[2 * i], m->x, (int)m->zero_off_c, m->h, C * 2, rows, n, 1, false, st);
+        if (rc != AZ_OK) return rc;
+        rc = launch_conv(m->convs[2 * i + 1], m->h, (int)m->zero_off_c, m->y, C * 2, rows, n, 0, false, st);
+        if (rc != AZ_OK) return rc;
+        const float* gate = nullptr;
+        if (c.use_se) {
+            hipLaunchKernelGGL(k_se_gate_layer, dim3(boards), dim3(256), (size_t)(C + c.se_hidden) * 4, st, (const uint16_t*)m->y, np, C, c.se_hidden,
+                               m->se[4 * i], m->se[4 * i + 1], m->se[4 * i + 2], m->se[4 * i + 3], m->gate);
+            gate = m->gate;
+        }
+        hipLaunchKernelGGL(k_scale_residual, egrid, dim3(256), 0, st, (const uint4*)m->y, gate, (uint4*)m->x, rows, np, C);
+    }
+    rc = launch_conv(m->head, m->x, (int)m->zero_off_c, (char*)hq, 2 * m->q * 2, rows, n, 1, true, st);
+    if (rc != AZ_OK) return rc;
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return fail(AZ_ERR_HIP, std::string("bf16 layer path: ") + hipGetErrorString(err));
+    return AZ_OK;
+}
+
+}  // namespace az

@@ -27,13 +27,11 @@
 #include <vector>
 
 #include "az_net.h"
+#include "az_mfma_gemm.cuh"
 
 namespace az {
 int fail(int code, const std::string& msg);
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 struct TowerParams {
     int n, np, TB, rows, blocks, use_se, hid, cin_pad, q;
@@ -69,359 +67,6 @@ struct TowerParams {
 #define STAMP(slot) do {} while (0)
 #endif
 
-__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
-    bf16x2 v = {(__bf16)a, (__bf16)b};
-    return __builtin_bit_cast(uint32_t, v);
-}
-// Makes a value opaque to the optimiser at this point, so address arithmetic derived from it is
-// recomputed where it is used instead of being hoisted out of the layer loop and spilled.
-__device__ __forceinline__ int opaque(int x) {
-    asm volatile("" : "+v"(x));
-    return x;
-}
-__device__ __forceinline__ float bf16_lo(uint32_t u) { return __uint_as_float(u << 16); }
-__device__ __forceinline__ float bf16_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
-__device__ __forceinline__ uint16_t to_bf16(float a) {
-    __bf16 v = (__bf16)a;
-    return __builtin_bit_cast(uint16_t, v);
-}
-
-// Asynchronous global -> LDS copy of one packed weight tile (nvec 16-byte vectors, a multiple of 64):
-// every wave-instruction moves 1 KiB (64 lanes x 16 B) straight into LDS, no staging registers.
-template <int NW>
-__device__ __forceinline__ void stage_tile(const uint4* __restrict__ src, char* dst, int nvec, int lane, int wave) {
-    const int nchunks = nvec >> 6;
-    for (int c = wave; c < nchunks; c += NW) {
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + c * 64 + lane),
-                                         (__attribute__((address_space(3))) void*)(dst + c * 1024), 16, 0, 0);
-    }
-}
-
-// Per-lane coordinates inside the workgroup tile. Every phase of the kernel re-derives them from an
-// opaque copy of threadIdx.x, so nothing computed from them is hoisted across the big layer loop
-// (the optimiser otherwise precomputes hundreds of addresses there and spills them).
-// A wave owns 16*MI positions (rows of the activation image) and 16*NI output channels. In every
-// 16x16 MFMA tile the lane holds position lr and the four channels 4*kq..4*kq+3 of the tile; tiles
-// 2p and 2p+1 are packed so that together they give the lane 8 consecutive channels (see pack_conv).
-#define AZ_LANE_GEO(MI_, NI_, WN_)                                                                \
-    const int t_ = opaque((int)threadIdx.x);                                                      \
-    const int lane = t_ & 63, wave = t_ >> 6, wm = wave / (WN_), wn = wave - wm * (WN_);          \
-    const int lr = lane & 15, kq = lane >> 4;                                                     \
-    const int row_base = wm * (16 * (MI_)), col0 = wn * ((NI_) * 16);                             \
-    (void)row_base; (void)col0; (void)lr; (void)kq; (void)wave
-
-struct TileGeo {   // wave-uniform facts about the workgroup's tile
-    int n, np, vrows;
-    unsigned recip_np, recip_n;
-};
-
-// LDS byte offsets (from `act`) of the lane's activation fragments for k-step (tap, cc): position
-// row + tap shift, 8 channels at 32*cc + 8*kq. Taps that leave the board, rows past the valid ones and
-// padding k-steps (tap >= ntaps) read the zero row.
-template <int MI>
-__device__ __forceinline__ void frag_offsets(int (&out)[MI], const int (&ry)[MI], const int (&rx)[MI], const int (&roff)[MI], int tap, int cc,
-                                             int ntaps, bool three, int n, int in_stride, int zoff) {
-    const int dy = three ? tap / 3 - 1 : 0, dx = three ? tap - (tap / 3) * 3 - 1 : 0;
-    const int shift = (dy * n + dx) * in_stride + cc * 64;
-    const bool tap_ok = tap < ntaps;
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-        const int yy = ry[mi] + dy, xx = rx[mi] + dx;
-        const bool ok = tap_ok & ((unsigned)yy < (unsigned)n) & ((unsigned)xx < (unsigned)n);
-        out[mi] = (ok ? roff[mi] + shift : zoff + cc * 64);
-    }
-}
-
-// Implicit GEMM acc[mi][ni] += W(16 channels x K) * X(K x 16 positions) over `nksteps` (even) k-steps of
-// 32 input channels, `kpt` k-steps per 3x3 tap. Weight tiles (two k-steps each) are streamed from `wg`
-// through the two LDS buffers at bbuf. The workgroup barrier of a tile sits between its two k-steps:
-// by then every wave holds the tile's last fragments in registers, so the buffer can be refilled (two
-// tiles ahead) and the MFMAs of the second k-step run while the first fragments of the next tile are
-// fetched -- the matrix pipe never waits for LDS at a tile boundary.
-template <int MI, int NI, int WM, int WN, int NCOLS, bool SAME_TAP>
-__device__ __forceinline__ void gemm_taps(f32x4 (&acc)[MI][NI], const uint4* __restrict__ wg, int nksteps, int kpt, int ntaps, bool three,
-                                          const char* act, int in_stride, const char* zrow, char* bbuf, const TileGeo& g) {
-    constexpr int NW = WM * WN;
-    constexpr int N = NCOLS;
-    constexpr int tile_bytes = 64 * N * 2, nvec = tile_bytes / 16, kstep_bytes = tile_bytes / 2;
-    constexpr int NCHUNK = nvec / 64;                 // 1 KiB pieces per weight tile
-    constexpr int PW = (NCHUNK + NW - 1) / NW;        // pieces per wave
-    AZ_LANE_GEO(MI, NI, WN);
-    const int ntiles = nksteps >> 1;
-    stage_tile<NW>(wg, bbuf, nvec, lane, wave);
-    if (ntiles > 1) stage_tile<NW>(wg + nvec, bbuf + tile_bytes, nvec, lane, wave);
-    // Tiles 2.. go through registers: fetched two tiles ahead, written to LDS one tile ahead.
-    constexpr bool RAGGED = (NCHUNK % NW) != 0;       // the last piece round does not cover every wave
-    uint4 stg[PW];
-    const uint4* wsrc = wg + lane + wave * 64;        // this lane's vector of piece `wave` of tile 0
-#pragma unroll
-    for (int i = 0; i < PW; ++i) {
-        stg[i] = make_uint4(0, 0, 0, 0);
-        if (ntiles > 2 && (!RAGGED || wave + i * NW < NCHUNK)) stg[i] = wsrc[(size_t)2 * nvec + i * NW * 64];
-    }
-    int ry[MI], rx[MI], roff[MI];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-        const int row = row_base + mi * 16 + lr;
-        const int b = (row * g.recip_np) >> 16, p = row - b * g.np;
-        ry[mi] = (p * g.recip_n) >> 16;
-        rx[mi] = p - ry[mi] * g.n;
-        if (row >= g.vrows) ry[mi] = -64;   // fails every bounds check
-        roff[mi] = row * in_stride + kq * 16;
-    }
-    const int zoff = (int)(zrow - act) + kq * 16;
-    const int woff = ((wn * NI) * 64 + lane) * 16;   // this wave's first channel tile inside a k-step image
-    const int soff = (wave * 64 + lane) * 16;        // where this lane's staged vector of piece `wave` goes
-    int tap = 0, cc = 0;   // cursor: the next k-step whose offsets are to be computed
-    int ap0[MI], ap1[MI];
-    frag_offsets<MI>(ap0, ry, rx, roff, tap, cc, ntaps, three, g.n, in_stride, zoff);
-    if (SAME_TAP) {
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) ap1[mi] = ap0[mi] + 64;
-        cc += 2;
-    } else {
-        if (++cc == kpt) { cc = 0; ++tap; }
-        frag_offsets<MI>(ap1, ry, rx, roff, tap, cc, ntaps, three, g.n, in_stride, zoff);
-        ++cc;
-    }
-    if (cc >= kpt) { cc = 0; ++tap; }
-    // tiles 0 and 1 have landed; the PW register fetches issued after them may still fly (the counter retires in order)
-    if (!RAGGED && ntiles > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    bf16x8 a0[MI], b0[NI], a1[MI], b1[NI];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) a0[mi] = *(const bf16x8*)(act + ap0[mi]);
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) b0[ni] = *(const bf16x8*)(bbuf + woff + ni * 1024);
-    for (int t = 0; t + 1 < ntiles; ++t) {
-        char* X = bbuf + (t & 1) * tile_bytes;
-        const char* Y = bbuf + ((t + 1) & 1) * tile_bytes;
-        // ---- first k-step: fetch the second k-step's fragments meanwhile
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) a1[mi] = *(const bf16x8*)(act + ap1[mi]);
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) b1[ni] = *(const bf16x8*)(X + kstep_bytes + woff + ni * 1024);
-        frag_offsets<MI>(ap0, ry, rx, roff, tap, cc, ntaps, three, g.n, in_stride, zoff);   // next tile
-        if (SAME_TAP) {
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) ap1[mi] = ap0[mi] + 64;
-            cc += 2;
-        } else {
-            if (++cc == kpt) { cc = 0; ++tap; }
-            frag_offsets<MI>(ap1, ry, rx, roff, tap, cc, ntaps, three, g.n, in_stride, zoff);
-            ++cc;
-        }
-        if (cc >= kpt) { cc = 0; ++tap; }
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[ni], a0[mi], acc[mi][ni], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < MI * NI; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            if (i < MI + NI) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-        // ---- tile boundary: X is free once every wave has its fragments; tile t+1 is complete in Y
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
-        __builtin_amdgcn_sched_barrier(0);
-        if (t + 2 < ntiles) {   // tile t+2 (fetched a tile ago) -> X; start fetching tile t+3
-#pragma unroll
-            for (int i = 0; i < PW; ++i)
-                if (!RAGGED || wave + i * NW < NCHUNK) *(uint4*)(X + soff + i * NW * 1024) = stg[i];
-            if (t + 3 < ntiles) {
-#pragma unroll
-                for (int i = 0; i < PW; ++i)
-                    if (!RAGGED || wave + i * NW < NCHUNK) stg[i] = wsrc[(size_t)(t + 3) * nvec + i * NW * 64];
-            }
-        }
-        // ---- second k-step: fetch the first fragments of the next tile meanwhile
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) a0[mi] = *(const bf16x8*)(act + ap0[mi]);
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) b0[ni] = *(const bf16x8*)(Y + woff + ni * 1024);
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[ni], a1[mi], acc[mi][ni], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < MI * NI; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            if (i < MI + NI) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-    }
-    {   // last tile
-        const char* X = bbuf + ((ntiles - 1) & 1) * tile_bytes;
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) a1[mi] = *(const bf16x8*)(act + ap1[mi]);
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) b1[ni] = *(const bf16x8*)(X + kstep_bytes + woff + ni * 1024);
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[ni], a0[mi], acc[mi][ni], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < MI * NI; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            if (i < MI + NI) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[ni], a1[mi], acc[mi][ni], 0, 0, 0);
-    }
-}
-
-// The same GEMM for layers whose taps span an even number KPT of k-steps (every layer with C >= 64): the
-// tile loop is unrolled over the KPT/2 tiles of a tap, so the channel offsets are instruction immediates
-// and the only per-tap vector work is one select per fragment row between the shifted position and the
-// zero row (from a per-lane 9-bit mask of the taps that stay on the board).
-template <int MI, int NI, int WM, int WN, int NCOLS, int KPT>
-__device__ __forceinline__ void gemm_conv(f32x4 (&acc)[MI][NI], const uint4* __restrict__ wg, int ntaps, bool three, const char* act,
-                                          int in_stride, const char* zrow, char* bbuf, const TileGeo& g) {
-    constexpr int NW = WM * WN;
-    constexpr int TPT = KPT / 2;                      // tiles per tap
-    constexpr int tile_bytes = 64 * NCOLS * 2, nvec = tile_bytes / 16, kstep_bytes = tile_bytes / 2;
-    constexpr int NCHUNK = nvec / 64;                 // 1 KiB pieces per weight tile
-    constexpr int PW = (NCHUNK + NW - 1) / NW;        // pieces per wave
-    constexpr bool RAGGED = (NCHUNK % NW) != 0;       // the last piece round does not cover every wave
-    static_assert(KPT % 2 == 0, "taps must cover whole tiles");
-    AZ_LANE_GEO(MI, NI, WN);
-    const int ntiles = ntaps * TPT;
-    stage_tile<NW>(wg, bbuf, nvec, lane, wave);
-    if (ntiles > 1) stage_tile<NW>(wg + nvec, bbuf + tile_bytes, nvec, lane, wave);
-    // Tiles 2.. go through registers: fetched two tiles ahead, written to LDS one tile ahead.
-    uint4 stg[PW];
-    const uint4* wsrc = wg + lane + wave * 64;        // this lane's vector of piece `wave` of tile 0
-#pragma unroll
-    for (int i = 0; i < PW; ++i) {
-        stg[i] = make_uint4(0, 0, 0, 0);
-        if (ntiles > 2 && (!RAGGED || wave + i * NW < NCHUNK)) stg[i] = wsrc[(size_t)2 * nvec + i * NW * 64];
-    }
-    int roff[MI], vmask[MI];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-        const int row = row_base + mi * 16 + lr;
-        const int b = (row * g.recip_np) >> 16, p = row - b * g.np;
-        const int y = (p * g.recip_n) >> 16, x = p - y * g.n;
-        int m = 0;
-        if (row < g.vrows) {
-            if (three) {
-#pragma unroll
-                for (int tp = 0; tp < 9; ++tp) {
-                    const int yy = y + tp / 3 - 1, xx = x + tp % 3 - 1;
-                    if ((unsigned)yy < (unsigned)g.n && (unsigned)xx < (unsigned)g.n) m |= 1 << tp;
-                }
-            } else {
-                m = 1;
-            }
-        }
-        vmask[mi] = m;
-        roff[mi] = row * in_stride + kq * 16;
-    }
-    const int zbase = (int)(zrow - act);
-    const int woff = ((wn * NI) * 64 + lane) * 16;   // this wave's first channel tile inside a k-step image
-    const int soff = (wave * 64 + lane) * 16;        // where this lane's staged vector of piece `wave` goes
-    int apc[MI], apn[MI];                            // fragment offsets of the current / next tap (channel offset 0)
-    auto tap_offsets = [&](int (&out)[MI], int tap) {
-        const int dy = three ? tap / 3 - 1 : 0, dx = three ? tap - (tap / 3) * 3 - 1 : 0;
-        const int shift = (dy * g.n + dx) * in_stride;
-        const int bit = tap < ntaps ? 1 << tap : 0;
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-            // A lane whose tap leaves the board reads zeros from the spot of the zero region that has the banks of
-            // the address it would have read (the region is 256-byte aligned), so the redirection adds no conflict.
-            const int reg = roff[mi] + shift;
-            out[mi] = (vmask[mi] & bit) ? reg : zbase + (reg & 255);
-        }
-    };
-    tap_offsets(apc, 0);
-    // tiles 0 and 1 have landed; the PW register fetches issued after them may still fly (the counter retires in order)
-    if (!RAGGED && ntiles > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    bf16x8 a0[MI], b0[NI], a1[MI], b1[NI];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) a0[mi] = *(const bf16x8*)(act + apc[mi]);
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) b0[ni] = *(const bf16x8*)(bbuf + woff + ni * 1024);
-    int t = 0;
-    for (int tap = 0; tap < ntaps; ++tap) {
-        tap_offsets(apn, tap + 1);
-#pragma unroll
-        for (int u = 0; u < TPT; ++u, ++t) {
-            const int par = (t & 1) * tile_bytes;
-            char* X = bbuf + par;
-            const char* Y = bbuf + (tile_bytes - par);
-            const char* xb = X + woff;
-            const char* yb = Y + woff;
-            // ---- first k-step: fetch the second k-step's fragments meanwhile
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) a1[mi] = *(const bf16x8*)(act + apc[mi] + (u * 128 + 64));
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) b1[ni] = *(const bf16x8*)(xb + kstep_bytes + ni * 1024);
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[ni], a0[mi], acc[mi][ni], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < MI * NI; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if (i < MI + NI) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-            // ---- tile boundary: X is free once every wave has its fragments; tile t+1 is complete in Y
-            __builtin_amdgcn_sched_barrier(0);
-            __syncthreads();
-            __builtin_amdgcn_sched_barrier(0);
-            // tile t+2 (fetched a tile ago) -> X, then fetch tile t+3 into the same registers; both are spread over
-            // the MFMAs below (issued together, 24 KiB of LDS stores and of fetches queue up in the CU's store and
-            // vector-memory paths and hold the in-order instruction streams behind them). Past the last tiles the
-            // last tile is fetched and stored again: X is dead by then, the copies are never read.
-            {
-                const uint4* src = wsrc + (size_t)min(t + 3, ntiles - 1) * nvec;
-#pragma unroll
-                for (int i = 0; i < PW; ++i)
-                    if (!RAGGED || wave + i * NW < NCHUNK) {
-                        *(uint4*)(X + soff + i * NW * 1024) = stg[i];
-                        stg[i] = src[i * NW * 64];
-                    }
-            }
-            // ---- second k-step: fetch the first fragments of the next tile meanwhile (after the last tile: of
-            // the zero row and a stale buffer, never used)
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-                a0[mi] = u + 1 < TPT ? *(const bf16x8*)(act + apc[mi] + (u + 1) * 128) : *(const bf16x8*)(act + apn[mi]);
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) b0[ni] = *(const bf16x8*)(yb + ni * 1024);
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[ni], a1[mi], acc[mi][ni], 0, 0, 0);
-            // the PW global fetches are spread over the MFMAs: issued together they would queue up in the
-            // CU's vector-memory path and hold the in-order instruction streams behind them
-#pragma unroll
-            for (int i = 0; i < MI * NI; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if (i < MI + NI) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                if (i % (MI * NI / PW) == 1 && i / (MI * NI / PW) < PW) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-                if (i % (MI * NI / PW) == MI * NI / PW / 2 + 1 && i / (MI * NI / PW) < PW) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-            }
-        }
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) apc[mi] = apn[mi];
-    }
-}
-
-template <int MI, int NI>
-__device__ __forceinline__ void zero_acc(f32x4 (&acc)[MI][NI]) {
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[mi][ni][r] = 0.f;
-}
 
 // act <- bf16(f(acc + bias)) with f = relu or identity (bias may be null); optionally park the packed values
 // in xres (the residual stream: each thread's private slice). One 16-byte LDS store per tile pair.
@@ -618,7 +263,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_tower(TowerPara
 #endif
     for (int i = tid; i < ZBYTES / 4; i += NT) ((uint32_t*)zrow)[i] = 0;
     TileGeo g;
-    g.n = P.n; g.np = P.np; g.recip_np = P.recip_np; g.recip_n = P.recip_n;
+    g.row0 = 0; g.n = P.n; g.np = P.np; g.recip_np = P.recip_np; g.recip_n = P.recip_n;
     const int rows = P.rows_dev ? min(*P.rows_dev, P.rows) : P.rows;
     const int items = (rows + P.TB - 1) / P.TB;
     for (int item = blockIdx.x; item < items; item += gridDim.x) {
@@ -931,44 +576,13 @@ struct MfmaNet {
     int hq_rows = 0;
     uint4* xres = nullptr;   // residual-stream scratch for max_grid workgroups
     int max_grid = 0;
+    LayerNet* layers = nullptr;   // set instead of the fused tower's weights when the shape needs the layer-by-layer path
     // optional timing of the tower kernel with HIP events on the launch stream
     bool profiling = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     size_t ev_used = 0;
     long long prof_rows = 0;
 };
-
-static uint16_t f2bf(float f) {
-    uint32_t u;
-    memcpy(&u, &f, 4);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
-    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
-}
-
-// Pack folded weights w[cout][cin][taps] into the LDS image the weight fragments are read from, k-step after
-// k-step (32 input channels of one tap each; the count is padded to an even number with zeros):
-// [k-step][channel tile][lane][8 consecutive input channels]. Lane l of a fragment holds output channel row
-// l & 15 of the tile and input channels 8*(l >> 4).. of the k-step. Tile rows are assigned to output
-// channels so that the MFMA result gives a lane 8 consecutive channels over the tile pair (2p, 2p+1):
-// row r of tile 2p+e is channel 32*p + 8*(r >> 2) + 4*e + (r & 3).
-static std::vector<uint16_t> pack_conv(const std::vector<float>& w, int cout, int cin, int taps, int cin_pad, int ncols) {
-    const int kpt = cin_pad / 32, nks = (taps * kpt + 1) & ~1, ntile = ncols / 16;
-    std::vector<uint16_t> out((size_t)nks * ntile * 64 * 8, 0);
-    for (int s = 0; s < nks; ++s) {
-        const int tap = s / kpt, c0 = (s % kpt) * 32;
-        if (tap >= taps) continue;
-        for (int nt = 0; nt < ntile; ++nt)
-            for (int l = 0; l < 64; ++l) {
-                const int r = l & 15, co = 32 * (nt >> 1) + 8 * (r >> 2) + 4 * (nt & 1) + (r & 3);
-                if (co >= cout) continue;
-                for (int j = 0; j < 8; ++j) {
-                    const int ci = c0 + 8 * (l >> 4) + j;
-                    if (ci < cin) out[(((size_t)s * ntile + nt) * 64 + l) * 8 + j] = f2bf(w[((size_t)co * cin + ci) * taps + tap]);
-                }
-            }
-    }
-    return out;
-}
 
 template <typename T>
 static int up(MfmaNet* m, const std::vector<T>& v, T** out) {
@@ -980,10 +594,12 @@ static int up(MfmaNet* m, const std::vector<T>& v, T** out) {
     return AZ_OK;
 }
 
-bool mfma_supported(const az_net_config& c) {
+static bool fused_supported(const az_net_config& c) {
     const bool cok = c.channels == 32 || c.channels == 64 || c.channels == 128 || c.channels == 192;
     return cok && c.board_size <= 9 && c.board_size >= 2 && c.in_planes <= 64;
 }
+bool mfma_supported(const az_net_config& c) { return (fused_supported(c) || layers_supported(c)) && c.value_hidden >= 1; }
+bool mfma_is_fused(const MfmaNet* m) { return m->layers == nullptr; }
 
 static size_t se_blob_bytes(int C, int hid) {  // per block: w1, w2^T (bf16), b1, b2 (f32), padded to 1 KiB
     const size_t raw = (size_t)2 * hid * C * 2 + (size_t)(hid + C) * 4;
@@ -1011,29 +627,34 @@ int mfma_create(const az_net_config& c, const NetLayout& L, const float* Pm, Mfm
     m->cin_pad = c.in_planes <= 32 ? 32 : 64;
     m->q = q;
     m->NH = std::max(32, 2 * q);   // policy q + value q channels, in whole tile pairs
-    if (tower_lds_bytes(C, m->NH, m->TB, c.se_hidden) > 160 * 1024) { delete m; return fail(AZ_ERR_ARG, "bf16 MFMA path: LDS budget exceeded"); }
+    const bool fused = fused_supported(c);
+    if (fused && tower_lds_bytes(C, m->NH, m->TB, c.se_hidden) > 160 * 1024) { delete m; return fail(AZ_ERR_ARG, "bf16 MFMA path: LDS budget exceeded"); }
     std::vector<float> w, b;
     TowerParams& P = m->P;
     memset(&P, 0, sizeof(P));
+    if (!fused) {
+        int rcl = layers_create(c, L, Pm, &m->layers);
+        if (rcl != AZ_OK) { delete m; return rcl; }
+    }
     P.n = c.board_size; P.np = np; P.TB = m->TB; P.blocks = c.blocks; P.use_se = c.use_se; P.hid = c.se_hidden;
     P.cin_pad = m->cin_pad; P.q = q;
     P.recip_np = (65536 + np - 1) / np;
     P.recip_n = (65536 + c.board_size - 1) / c.board_size;
-    for (int row = 0; row < 512; ++row)
+    for (int row = 0; fused && row < 512; ++row)
         if ((((unsigned)row * P.recip_np) >> 16 != (unsigned)(row / np)) || (((unsigned)row * P.recip_n) >> 16 != (unsigned)(row / c.board_size))) {
             delete m;
             return fail(AZ_ERR_ARG, "reciprocal division check failed");
         }
     int rc;
 #define TRY(x) if ((rc = (x)) != AZ_OK) { mfma_destroy(m); return rc; }
-    {   // stem
+    if (fused) {   // stem
         fold_bn(Pm, L.stem_w, L.stem_bn, C, (int64_t)c.in_planes * 9, w, b);
         std::vector<uint16_t> pk = pack_conv(w, C, c.in_planes, 9, m->cin_pad, C);
         uint16_t* d; float* bd;
         TRY(up(m, pk, &d)); TRY(up(m, b, &bd));
         P.w_stem = (const uint4*)d; P.b_stem = bd;
     }
-    {   // tower
+    if (fused) {   // tower
         std::vector<uint16_t> all;
         std::vector<float> ball;
         const size_t blob_bytes = se_blob_bytes(C, c.se_hidden);
@@ -1067,7 +688,7 @@ int mfma_create(const az_net_config& c, const NetLayout& L, const float* Pm, Mfm
         TRY(up(m, ball, &f)); P.b_tower = f;
         TRY(up(m, blob, &bl)); P.se_blob = (const uint4*)bl; P.se_vecs = (int)(blob_bytes / 16);
     }
-    {   // fused head 1x1: columns [0,q) policy_head.0, [q,2q) value_head.0
+    if (fused) {   // fused head 1x1: columns [0,q) policy_head.0, [q,2q) value_head.0
         std::vector<float> wp, bp, wv, bv, wh((size_t)2 * q * C), bh(m->NH, 0.f);
         fold_bn(Pm, L.ph0_w, L.ph0_bn, q, C, wp, bp);
         fold_bn(Pm, L.vh0_w, L.vh0_bn, q, C, wv, bv);
@@ -1124,19 +745,21 @@ int mfma_create(const az_net_config& c, const NetLayout& L, const float* Pm, Mfm
     }
 #undef TRY
     // opt in to the large dynamic LDS size once
-    const size_t lds = tower_lds_bytes(C, m->NH, m->TB, c.se_hidden);
+    const size_t lds = fused ? tower_lds_bytes(C, m->NH, m->TB, c.se_hidden) : 0;
     hipError_t e = hipSuccess;
-    switch (C) {
+    switch (fused ? C : 0) {
         case 32: e = hipFuncSetAttribute((const void*)k_tower<32, 8, 1, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); break;
         case 64: e = hipFuncSetAttribute((const void*)k_tower<64, 4, 2, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); break;
         case 128: e = hipFuncSetAttribute((const void*)k_tower<128, 4, 2, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); break;
         case 192: e = hipFuncSetAttribute((const void*)k_tower<192, 4, 2, 96>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); break;
     }
     if (e != hipSuccess) { mfma_destroy(m); return fail(AZ_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); }
-    const size_t vt = ((size_t)4 * q * np + 4 * c.value_hidden) * 4;
-    e = hipFuncSetAttribute((const void*)k_value_tail<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vt);
-    if (e != hipSuccess) { mfma_destroy(m); return fail(AZ_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); }
-    {   // one workgroup per CU (LDS-bound), each striding over the board groups
+    if (!m->w4p) {   // scalar value tail (hidden size above 256): its input image must fit LDS
+        const size_t vt = ((size_t)4 * q * np + 4 * c.value_hidden) * 4;
+        e = vt <= 160 * 1024 ? hipFuncSetAttribute((const void*)k_value_tail<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)vt) : hipErrorInvalidValue;
+        if (e != hipSuccess) { mfma_destroy(m); return fail(AZ_ERR_ARG, "bf16 MFMA path: value head too large (value_hidden > 256 on this board size)"); }
+    }
+    if (fused) {   // one workgroup per CU (LDS-bound), each striding over the board groups
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, c.device) != hipSuccess) { mfma_destroy(m); return fail(AZ_ERR_HIP, "hipGetDeviceProperties"); }
         m->max_grid = std::max(1, prop.multiProcessorCount);
@@ -1164,6 +787,7 @@ static int base_event(int device, hipEvent_t* out) {
 
 int mfma_set_grid_limit(MfmaNet* m, int workgroups) {
     if (workgroups < 1) return fail(AZ_ERR_ARG, "workgroup limit must be >= 1");
+    if (m->layers) return AZ_OK;   // the layer path has no resident workgroups
     if (workgroups == m->max_grid) return AZ_OK;
     if (hipDeviceSynchronize() != hipSuccess) return fail(AZ_ERR_HIP, "hipDeviceSynchronize");
     uint4* x = nullptr;
@@ -1222,12 +846,67 @@ void mfma_destroy(MfmaNet* m) {
     for (void* p : m->allocs) (void)hipFree(p);
     if (m->hq) (void)hipFree(m->hq);
     if (m->xres) (void)hipFree(m->xres);
+    if (m->layers) layers_destroy(m->layers);
     delete m;
+}
+
+// Policy and value tails over the head activations hq [rows][np][2q].
+static void run_tails(MfmaNet* m, const uint16_t* hq_in, int rows, const int* rows_dev, float* logits, float* values, hipStream_t st) {
+    const az_net_config& c = m->cfg;
+    const int np = c.board_size * c.board_size, q = m->q;
+    hipLaunchKernelGGL((k_policy_tail<8>), dim3((rows + 7) / 8), dim3(256), (size_t)8 * 2 * np * 4, st, hq_in, m->w3, m->b3, m->wfcT, m->bfc, logits, rows,
+                       np, q, rows_dev);
+    if (m->w4p) {
+        const dim3 vg((rows + 15) / 16);
+        const uint4* wp = (const uint4*)m->w4p;
+        switch ((m->v_ntiles + 3) / 4) {
+            case 1: hipLaunchKernelGGL((k_value_tail_mfma<1>), vg, dim3(256), 0, st, hq_in, wp, m->b4p, m->w6p, m->b6, values, rows, np, q, m->v_nks, m->v_ntiles, m->v_recip, rows_dev); break;
+            case 2: hipLaunchKernelGGL((k_value_tail_mfma<2>), vg, dim3(256), 0, st, hq_in, wp, m->b4p, m->w6p, m->b6, values, rows, np, q, m->v_nks, m->v_ntiles, m->v_recip, rows_dev); break;
+            case 3: hipLaunchKernelGGL((k_value_tail_mfma<3>), vg, dim3(256), 0, st, hq_in, wp, m->b4p, m->w6p, m->b6, values, rows, np, q, m->v_nks, m->v_ntiles, m->v_recip, rows_dev); break;
+            default: hipLaunchKernelGGL((k_value_tail_mfma<4>), vg, dim3(256), 0, st, hq_in, wp, m->b4p, m->w6p, m->b6, values, rows, np, q, m->v_nks, m->v_ntiles, m->v_recip, rows_dev); break;
+        }
+    } else {
+        const size_t vt = ((size_t)4 * q * np + 4 * c.value_hidden) * 4;
+        hipLaunchKernelGGL((k_value_tail<4>), dim3((rows + 3) / 4), dim3(256), vt, st, hq_in, m->w4T, m->b4, m->w6, m->b6, values, rows, np, q,
+                           c.value_hidden, rows_dev);
+    }
 }
 
 int mfma_forward(MfmaNet* m, const void* feat, int rows, const int* rows_dev, float* logits, float* values, hipStream_t st) {
     const az_net_config& c = m->cfg;
     const int C = c.channels, np = c.board_size * c.board_size, q = m->q;
+    if (m->layers) {
+        if (rows_dev) return fail(AZ_ERR_STATE, "az_net_forward_indirect: not available for networks on the layer-by-layer path");
+        const int chunk = layers_chunk_boards(m->layers), A = np + 1;
+        if (m->hq_rows < chunk) {
+            if (hipDeviceSynchronize() != hipSuccess) return fail(AZ_ERR_HIP, "hipDeviceSynchronize");
+            if (m->hq) (void)hipFree(m->hq);
+            m->hq = nullptr;
+            if (hipMalloc((void**)&m->hq, (size_t)chunk * np * 2 * q * 2) != hipSuccess) return fail(AZ_ERR_HIP, "hipMalloc (head scratch)");
+            m->hq_rows = chunk;
+        }
+        std::pair<hipEvent_t, hipEvent_t>* evl = nullptr;
+        if (m->profiling) {
+            if (m->ev_used == m->events.size()) {
+                hipEvent_t a, b;
+                if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return fail(AZ_ERR_HIP, "hipEventCreate");
+                m->events.emplace_back(a, b);
+            }
+            evl = &m->events[m->ev_used++];
+            m->prof_rows += rows;
+            (void)hipEventRecord(evl->first, st);
+        }
+        for (int off = 0; off < rows; off += chunk) {
+            const int nb = std::min(chunk, rows - off);
+            int rc = layers_tower(m->layers, (const uint16_t*)feat + (size_t)off * np * 32, nb, m->hq, st);
+            if (rc != AZ_OK) return rc;
+            run_tails(m, m->hq, nb, nullptr, logits + (size_t)off * A, values + off, st);
+        }
+        if (evl) (void)hipEventRecord(evl->second, st);
+        hipError_t errl = hipGetLastError();
+        if (errl != hipSuccess) return fail(AZ_ERR_HIP, std::string("bf16 forward (layers): ") + hipGetErrorString(errl));
+        return AZ_OK;
+    }
     if (rows > m->hq_rows) {  // scratch for the head activations grows outside the steady state
         if (hipDeviceSynchronize() != hipSuccess) return fail(AZ_ERR_HIP, "hipDeviceSynchronize");
         if (m->hq) (void)hipFree(m->hq);
@@ -1275,22 +954,7 @@ int mfma_forward(MfmaNet* m, const void* feat, int rows, const int* rows_dev, fl
         default: return fail(AZ_ERR_ARG, "unsupported channel count");
     }
     if (ev) (void)hipEventRecord(ev->second, st);
-    hipLaunchKernelGGL((k_policy_tail<8>), dim3((rows + 7) / 8), dim3(256), (size_t)8 * 2 * np * 4, st, m->hq, m->w3, m->b3, m->wfcT, m->bfc, logits, rows,
-                       np, q, rows_dev);
-    if (m->w4p) {
-        const dim3 vg((rows + 15) / 16);
-        const uint4* wp = (const uint4*)m->w4p;
-        switch ((m->v_ntiles + 3) / 4) {
-            case 1: hipLaunchKernelGGL((k_value_tail_mfma<1>), vg, dim3(256), 0, st, m->hq, wp, m->b4p, m->w6p, m->b6, values, rows, np, q, m->v_nks, m->v_ntiles, m->v_recip, rows_dev); break;
-            case 2: hipLaunchKernelGGL((k_value_tail_mfma<2>), vg, dim3(256), 0, st, m->hq, wp, m->b4p, m->w6p, m->b6, values, rows, np, q, m->v_nks, m->v_ntiles, m->v_recip, rows_dev); break;
-            case 3: hipLaunchKernelGGL((k_value_tail_mfma<3>), vg, dim3(256), 0, st, m->hq, wp, m->b4p, m->w6p, m->b6, values, rows, np, q, m->v_nks, m->v_ntiles, m->v_recip, rows_dev); break;
-            default: hipLaunchKernelGGL((k_value_tail_mfma<4>), vg, dim3(256), 0, st, m->hq, wp, m->b4p, m->w6p, m->b6, values, rows, np, q, m->v_nks, m->v_ntiles, m->v_recip, rows_dev); break;
-        }
-    } else {
-        const size_t vt = ((size_t)4 * q * np + 4 * c.value_hidden) * 4;
-        hipLaunchKernelGGL((k_value_tail<4>), dim3((rows + 3) / 4), dim3(256), vt, st, m->hq, m->w4T, m->b4, m->w6, m->b6, values, rows, np, q,
-                           c.value_hidden, rows_dev);
-    }
+    run_tails(m, m->hq, rows, rows_dev, logits, values, st);
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return fail(AZ_ERR_HIP, std::string("bf16 forward: ") + hipGetErrorString(err));
 #ifdef AZ_STAMP

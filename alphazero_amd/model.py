@@ -140,6 +140,9 @@ class NativeNet:
             raise ValueError(f"parameter blob has {p.size} values, network needs {want}")
         with torch.cuda.device(self.device):
             N.check(self.L.az_net_load(h, p.ctypes.data_as(C.c_void_p), p.size), "az_net_load")
+        f = C.c_int32()
+        N.check(self.L.az_net_is_fused(h, C.byref(f)), "az_net_is_fused")
+        self.fused = bool(f.value)     # single fused tower kernel (forward_indirect available) vs layer by layer
 
     def close(self):
         if getattr(self, "_h", None):

@@ -170,7 +170,7 @@ class _Lane:
             else:
                 self.feat_buf = torch.empty((self.max_rows, self.eng.Cp, cfg.board_size, cfg.board_size), dtype=torch.float32, device=self.dev)
             # with the native bf16 network the batches of a search are enqueued without host round trips
-            self.async_search = self.net is not None and precision == "bf16"
+            self.async_search = self.net is not None and precision == "bf16" and self.net.fused
             if self.async_search:
                 self.eng.set_async(True)
                 self.rows_dev = self.eng.rows_device()
@@ -391,7 +391,7 @@ class BatchedSelfPlay:
     def set_async(self, enable: bool):
         """Switch between enqueueing the batches of a search without host round trips and one round trip per batch."""
         for ln in self.lanes:
-            ok = bool(enable) and ln.net is not None and ln.layout == N.AZ_FEAT_BF16_NHWC
+            ok = bool(enable) and ln.net is not None and ln.layout == N.AZ_FEAT_BF16_NHWC and ln.net.fused
             ln.async_search = ok
             ln.eng.set_async(ok)
 

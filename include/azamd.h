@@ -153,6 +153,9 @@ int az_net_load(az_net* net, const float* params_host, int64_t count);
 int az_net_forward(az_net* net, const void* feat_dev, int32_t rows, float* logits_dev, float* values_dev,
                    void* stream);
 
+/* *fused = 1 if the bf16 network runs as the single fused tower kernel (boards up to 9x9, up to 192 channels), 0 if
+ * it runs layer by layer (larger boards, 256 channels) or in float32; az_net_forward_indirect needs the fused kind. */
+int az_net_is_fused(az_net* net, int32_t* fused);
 /* Same with the row count read on the device from *rows_dev (<= max_rows): no host round trip. */
 int az_net_forward_indirect(az_net* net, const void* feat_dev, const int32_t* rows_dev, int32_t max_rows,
                             float* logits_dev, float* values_dev, void* stream);

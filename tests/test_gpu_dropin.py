@@ -169,3 +169,22 @@ def test_pipelined_lanes_play_the_same_games(lanes):
                 assert np.array_equal(xa, xb)
     sa, sb = one.collect_samples(), many.collect_samples()
     assert len(sa[0]) == len(sb[0]) and sa[1:] == sb[1:]
+
+
+def test_lockstep_selfplay_on_19x19_layer_path():
+    """19x19 (3 points per lane on the board kernels, network layer by layer): a few lockstep moves run, every
+    game's visit counts add up to the simulation count, and the search falls back to one round trip per batch."""
+    import torch
+    from alphazero_amd.model import AlphaZeroNet
+    from alphazero_amd.selfplay import BatchedSelfPlay, SelfPlayConfig
+    torch.manual_seed(5)
+    net = AlphaZeroNet(board_size=19, channels=64, num_blocks=1).eval().cuda()
+    cfg = SelfPlayConfig(board_size=19, mcts_simulations=12, mcts_inference_batch=4, mcts_topk_expand=16)
+    sp = BatchedSelfPlay(net, cfg, games=5, seed0=2)
+    assert not sp.async_search and not sp.net.fused
+    sp.begin(num_games=5)
+    for _ in range(3):
+        sp.step()
+    assert sp.counters["sims"] == 3 * 5 * 12 and sp.counters["moves"] == 15
+    for bits, caps, pi32, to_play, diff in sp.log:
+        assert pi32.shape == (5, 362) and np.allclose(pi32.sum(axis=1), 1.0, atol=1e-5)

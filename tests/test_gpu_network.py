@@ -102,3 +102,36 @@ def test_unsupported_bf16_shape_is_refused():
     net = AlphaZeroNet(board_size=19, channels=32, num_blocks=1).to("cuda:0")
     with pytest.raises(N.NativeError):
         net.native("bf16")
+
+
+LAYERED = [dict(board_size=13, channels=64, num_blocks=2), dict(board_size=19, channels=128, num_blocks=2),
+           dict(board_size=9, channels=256, num_blocks=2, value_hidden_dim=64),
+           dict(board_size=19, channels=256, num_blocks=1, use_se=False), dict(board_size=19, channels=192, num_blocks=1, history_len=4)]
+
+
+@pytest.mark.parametrize("kw", LAYERED, ids=lambda k: f"n{k['board_size']}_c{k['channels']}")
+def test_bf16_layer_path(kw):
+    """Boards above 9x9 and 256-channel towers run layer by layer (activations in HBM): same 1e-2 bound against the
+    float32 torch module, same independence of a position's output from its neighbours in the batch."""
+    from alphazero_amd.model import AlphaZeroNet
+    import stubnets
+    torch.manual_seed(11)
+    net = AlphaZeroNet(**kw).eval()
+    n, c = kw["board_size"], 2 * kw.get("history_len", 8) + 5
+    x = stubnets.synthetic_planes(9, c, n, seed=5)
+    with torch.inference_mode():
+        lg_t, v_t = net(torch.from_numpy(x))
+    dev = torch.device("cuda:0")
+    nn = net.to(dev).native("bf16")
+    assert not nn.fused
+    f = _to_nhwc_bf16(x).to(dev)
+    lg, v = nn(f)
+    e_lg, e_val = float((lg.cpu() - lg_t).abs().max()), float((v.cpu() - v_t).abs().max())
+    e_prob = float((lg.cpu().softmax(1) - lg_t.softmax(1)).abs().max())
+    print(f"layered {kw}: logit err {e_lg:.3g}, value err {e_val:.3g}, prob err {e_prob:.3g}")
+    assert e_lg <= 1e-2 and e_val <= 1e-2 and e_prob <= 1e-2
+    perm = torch.randperm(9)
+    lg_p, v_p = nn(f[perm].contiguous())
+    assert torch.equal(lg[perm], lg_p) and torch.equal(v[perm], v_p)
+    lg_1, v_1 = nn(f[4:5].contiguous())
+    assert torch.equal(lg[4:5], lg_1) and torch.equal(v[4:5], v_1)

@@ -8,10 +8,11 @@ def main():
     rows = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     ch = int(sys.argv[2]) if len(sys.argv) > 2 else 192
     blocks = int(sys.argv[3]) if len(sys.argv) > 3 else 12
+    n = int(sys.argv[4]) if len(sys.argv) > 4 else 9
     torch.manual_seed(0)
-    net = AlphaZeroNet(channels=ch, num_blocks=blocks).eval().to("cuda:0")
+    net = AlphaZeroNet(board_size=n, channels=ch, num_blocks=blocks).eval().to("cuda:0")
     nn = net.native("bf16")
-    f = (torch.rand((rows, 81, 32), device="cuda:0") < 0.3).to(torch.bfloat16)
+    f = (torch.rand((rows, n * n, 32), device="cuda:0") < 0.3).to(torch.bfloat16)
     f[:, :, 21:] = 0
     for _ in range(3):
         nn(f)
@@ -24,10 +25,10 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
-    macs = {(192, 12): 650.5e6, (64, 4): 25.4e6}.get((ch, blocks))
+    macs = {(192, 12, 9): 650.5e6, (64, 4, 9): 25.4e6}.get((ch, blocks, n))
     if macs is None:
-        macs = 81 * 9 * 21 * ch + blocks * 2 * 81 * 9 * ch * ch
+        macs = n * n * 9 * 21 * ch + blocks * 2 * n * n * 9 * ch * ch
     fl = 2 * macs * rows
-    print(f"rows={rows} ch={ch} blocks={blocks}: {ms:.3f} ms/forward, {rows/ms*1e3:.0f} pos/s, {fl/ms/1e9:.1f} TFLOP/s")
+    print(f"rows={rows} ch={ch} blocks={blocks} board={n} fused={nn.fused}: {ms:.3f} ms/forward, {rows/ms*1e3:.0f} pos/s, {fl/ms/1e9:.1f} TFLOP/s")
 
 main()
