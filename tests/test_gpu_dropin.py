@@ -1,6 +1,7 @@
 """The upstream call surface (go_zero.GoState / MCTS / self-play loop) served by the device engine,
 checked against golden vectors recorded from the upstream Python code."""
 import json
+import os
 
 import numpy as np
 import pytest
@@ -188,3 +189,25 @@ def test_lockstep_selfplay_on_19x19_layer_path():
     assert sp.counters["sims"] == 3 * 5 * 12 and sp.counters["moves"] == 15
     for bits, caps, pi32, to_play, diff in sp.log:
         assert pi32.shape == (5, 362) and np.allclose(pi32.sum(axis=1), 1.0, atol=1e-5)
+
+
+def test_bench_line_contract():
+    """bench.py prints one JSON line with the fields the driver reads (small game count so it takes seconds)."""
+    import json as _json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--games", "192", "--lanes", "2",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = _json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["unit"] == "sims/s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"] == "bf16" and "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert d["value"] == pytest.approx(2 * 192 * 256 / (d["ms_per_step"] * 2e-3), rel=1e-3)
