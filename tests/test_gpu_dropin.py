@@ -211,3 +211,33 @@ def test_bench_line_contract():
     r = d["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert d["value"] == pytest.approx(2 * 192 * 256 / (d["ms_per_step"] * 2e-3), rel=1e-3)
+
+
+def test_full_length_selfplay_config2():
+    """BASELINE configs[1]: 9x9, 64ch x 4 blocks, 192 sims, 512 lockstep games, played to the end with slot refill
+    (768 games through 512 slots in two lanes). Size-independent properties: every game ends, by two passes or at
+    the 162-move cap or by resignation; per-game sample counts equal the number of moves searched; z is the
+    winner seen from the side to move; pi rows are distributions."""
+    import torch
+    from alphazero_amd.model import AlphaZeroNet
+    from alphazero_amd.selfplay import BatchedSelfPlay, SelfPlayConfig
+    torch.manual_seed(1)
+    net = AlphaZeroNet(board_size=9, channels=64, num_blocks=4).eval().cuda()
+    cfg = SelfPlayConfig(board_size=9, mcts_simulations=192, mcts_inference_batch=16, mcts_topk_expand=24)
+    sp = BatchedSelfPlay(net, cfg, games=512, seed0=100, lanes=2, tower_workgroups=1024)
+    samples, bw, ww, dd = sp.run(num_games=768)
+    assert bw + ww + dd == 768 and sorted(sp.finished) == list(range(768))
+    total = 0
+    for gid in (0, 1, 511, 512, 767):
+        traj, winner = sp.trajectory(gid)
+        assert 1 <= len(traj) <= 162 and winner in (-1, 0, 1)
+        for packed, capf, pi, player, difficulty in traj:
+            assert abs(float(pi.sum()) - 1.0) < 1e-5 and player in (-1, 1) and 0.01 <= difficulty <= 1.0
+    for gid in sp.finished:
+        total += sp.finished[gid][3] - sp.finished[gid][2]
+    assert len(samples) == total == sp.counters["moves"]
+    assert sp.counters["sims"] == 192 * sp.counters["moves"]
+    zs = np.array([s[2] for s in samples])
+    assert set(np.unique(zs)) <= {-1.0, 0.0, 1.0}
+    st = sp.eng.stats()
+    assert st["max_nodes"] <= 1 + 193 * 24 and st["max_depth"] <= 164
