@@ -69,6 +69,7 @@ SIGNATURES = {
     "az_net_set_tower_workgroups": (_I32, [_VP, _I32]),
     "az_net_profile": (_I32, [_VP, _I32, C.POINTER(C.c_double), C.POINTER(_I64), C.POINTER(_I64)]),
     "az_replay_gather": (_I32, [_VP, _VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _VP, _VP, _VP]),
+    "az_pack_planes": (_I32, [_VP, _I32, _I32, _I32, _I32, _VP, _VP, _VP]),
     "az_rng_create": (_I32, [_I32, C.POINTER(_VP)]),
     "az_rng_destroy": (_I32, [_VP]),
     "az_rng_seed": (_I32, [_VP, _I32, C.c_uint32]),

@@ -37,9 +37,39 @@ __global__ __launch_bounds__(256) void k_replay_gather(const uint8_t* __restrict
     const float* ps = pi + src * A;
     for (int i = threadIdx.x; i < A; i += blockDim.x) op[i] = i < np ? ps[pm[i]] : ps[np];
 }
+// to_tensor() planes (float32 [count][nbin+2][np]) -> the store's compact form: one thread per packed byte,
+// plus the two capture-plane values (their first element) per position.
+__global__ __launch_bounds__(256) void k_pack_planes(const float* __restrict__ planes, int count, int np, int nbin, int row_bytes,
+                                                     uint8_t* __restrict__ bits, float* __restrict__ caps) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= count * row_bytes) return;
+    const int s = i / row_bytes, byte = i - s * row_bytes;
+    const float* src = planes + (size_t)s * (nbin + 2) * np;
+    unsigned v = 0;
+    for (int k = 0; k < 8; ++k) {
+        const int bit = byte * 8 + k;
+        if (bit < nbin * np && src[bit] > 0.5f) v |= 0x80u >> k;
+    }
+    bits[i] = (uint8_t)v;
+    if (byte < 2) caps[s * 2 + byte] = src[(size_t)(nbin + byte) * np];
+}
 }  // namespace az
 
 using namespace az;
+
+extern "C" int az_pack_planes(const float* planes, int32_t count, int32_t board_size, int32_t history_len, int32_t row_bytes, uint8_t* bits,
+                              float* caps, void* stream) {
+    if (!planes || !bits || !caps) return fail(AZ_ERR_ARG, "null argument");
+    if (board_size < 2 || board_size > 19 || history_len < 1 || history_len > 16) return fail(AZ_ERR_ARG, "bad board_size / history_len");
+    const int np = board_size * board_size, nbin = 2 * history_len + 3;
+    if (row_bytes < (nbin * np + 7) / 8 || row_bytes < 2) return fail(AZ_ERR_ARG, "row_bytes too small for the packed planes");
+    if (count <= 0) return AZ_OK;
+    hipLaunchKernelGGL(k_pack_planes, dim3((count * row_bytes + 255) / 256), dim3(256), 0, (hipStream_t)stream, planes, count, np, nbin, row_bytes,
+                       bits, caps);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return fail(AZ_ERR_HIP, std::string("k_pack_planes: ") + hipGetErrorString(err));
+    return AZ_OK;
+}
 
 extern "C" int az_replay_gather(const uint8_t* bits, const float* caps, const float* pi, const int16_t* perm, const int32_t* idx,
                                 const int32_t* sym, int32_t count, int32_t board_size, int32_t history_len, int32_t row_bytes,

@@ -176,8 +176,7 @@ class _Lane:
                 self.rows_dev = self.eng.rows_device()
                 self.logits_buf = torch.empty((self.max_rows, self.A), dtype=torch.float32, device=self.dev)
                 self.values_buf = torch.empty((self.max_rows,), dtype=torch.float32, device=self.dev)
-            self._bitw = torch.tensor([128, 64, 32, 16, 8, 4, 2, 1], dtype=torch.int32, device=self.dev)
-        self.step_no = 0
+            self.step_no = 0
         self.inflight = None
 
     # ------------------------------------------------------------------ slots
@@ -336,14 +335,15 @@ class _Lane:
 
     def _pack_planes(self, planes):
         """Binary planes of to_tensor() (go.py:265-304: all but the two capture planes) as np.packbits would
-        pack them (row-major, most significant bit first), packed on the device before the copy to the host."""
-        G, H = self.G, self.o.cfg.history_len
-        b = (planes[:, : 2 * H + 3].reshape(G, -1) > 0.5).to(torch.int32)
-        pad = (-b.shape[1]) % 8
-        if pad:
-            b = torch.nn.functional.pad(b, (0, pad))
-        bits = (b.view(G, -1, 8) * self._bitw).sum(-1).to(torch.uint8)
-        caps = planes[:, 2 * H + 3:, 0, 0].contiguous()
+        pack them (row-major, most significant bit first), packed on the device (az_pack_planes) before the
+        copy to the host; the capture planes as one float each."""
+        G, H, n = self.G, self.o.cfg.history_len, self.o.cfg.board_size
+        row_bytes = ((2 * H + 3) * n * n + 7) // 8
+        bits = torch.empty((G, row_bytes), dtype=torch.uint8, device=self.dev)
+        caps = torch.empty((G, 2), dtype=torch.float32, device=self.dev)
+        N.check(N.lib().az_pack_planes(C.c_void_p(planes.data_ptr()), G, n, H, row_bytes, C.c_void_p(bits.data_ptr()),
+                                       C.c_void_p(caps.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                "az_pack_planes")
         return bits, caps
 
     def prune_log(self):

@@ -200,6 +200,11 @@ int az_replay_gather(const uint8_t* bits, const float* caps, const float* pi, co
                      const int32_t* sym, int32_t count, int32_t board_size, int32_t history_len, int32_t row_bytes,
                      float* out_states, float* out_pi, void* stream);
 
+/* The inverse direction: to_tensor() planes (float32 [count][2H+5][n][n], e.g. from az_rules_features) into the
+ * store's compact form, `bits` [count][row_bytes] and `caps` [count][2] (go.py:265-304 planes; numpy.packbits order). */
+int az_pack_planes(const float* planes, int32_t count, int32_t board_size, int32_t history_len, int32_t row_bytes, uint8_t* bits,
+                   float* caps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
