@@ -49,6 +49,8 @@ SIGNATURES = {
     "az_mcts_begin": (_I32, [_VP, _VP, _VP]),
     "az_mcts_select": (_I32, [_VP, _VP]),
     "az_mcts_pending": (_I32, [_VP, C.POINTER(_I32), _VP]),
+    "az_mcts_set_root_reuse": (_I32, [_VP, _I32]),
+    "az_mcts_gather_rows": (_I32, [_VP, C.POINTER(_I32), _VP]),
     "az_mcts_set_async": (_I32, [_VP, _I32]),
     "az_mcts_rows_device": (_I32, [_VP, C.POINTER(_VP)]),
     "az_mcts_gather": (_I32, [_VP, _VP, _I32, _VP]),

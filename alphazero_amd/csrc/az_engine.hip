@@ -65,8 +65,16 @@ struct Dev {
     int* row_off;     // [G+1]
     int* row_game; int* row_slot;  // [max_rows]
     uint8_t* row_legal;  // [max_rows][A]
-    int* ctl;         // [4] n_rows, error code, -, -
+    int* ctl;         // [4] rows to evaluate, error code, rows to gather (>= rows to evaluate: roots with carried-over logits come last), -
     long long* stats; // [8], filled by k_reduce_stats
+    // Root-evaluation reuse (rc_cap > 0): the root of the next search is the child played after this one, and that child was
+    // evaluated as a leaf of this search; its logits are kept so that a batch-invariant evaluator need not see it again.
+    int rc_cap;            // root children covered per game (0: off)
+    float* rc_logits;      // [G][rc_cap][A] logits of the root children expanded in the current search
+    uint8_t* rc_valid;     // [G][rc_cap]
+    float* root_logits;    // [G][A] logits carried over to the next root
+    uint8_t* root_cached;  // [G] root_logits holds the evaluation of the current root state
+    uint8_t* tree_live;    // [G] the tree in memory was searched from the state before the next move
     long long* gstats; // [G][8] per-game counters of the current search (no cross-workgroup atomics on the hot kernels)
 };
 
@@ -154,6 +162,7 @@ template <int PPL>
 __global__ __launch_bounds__(64) void k_reset(Dev d, const uint8_t* mask) {
     const int g = blockIdx.x, lane = threadIdx.x;
     if (mask && !mask[g]) return;
+    if (d.rc_cap && lane == 0) { d.root_cached[g] = 0; d.tree_live[g] = 0; }
     for (int i = lane; i < d.npad; i += 64) d.board[(size_t)g * d.npad + i] = 0;
     for (int i = lane; i < d.H * d.npad; i += 64) d.hist[(size_t)g * d.H * d.npad + i] = 0;
     if (lane == 0) {
@@ -216,6 +225,25 @@ __global__ __launch_bounds__(64) void k_play(Dev d, const int* actions, int* sta
         sc[SC_HIST] = min(sc[SC_HIST] + 1, d.H);
         d.hash[g] = s.hash;
         if (status) status[g] = 0;
+    }
+    if (d.rc_cap) {   // wave-uniform
+        const size_t nb = (size_t)g * d.max_nodes;
+        int ci = -1;
+        if (d.tree_live[g]) {
+            const int first = d.child_off[nb], nc = min((int)d.n_child[nb], d.rc_cap);
+            for (int c0 = 0; c0 < nc; c0 += 64) {
+                const int c = c0 + lane;
+                const bool hit = c < nc && d.action[nb + first + c] == a && d.rc_valid[(size_t)g * d.rc_cap + c];
+                const unsigned long long m = __ballot(hit);
+                if (m) { ci = c0 + __ffsll((long long)m) - 1; break; }
+            }
+        }
+        if (ci >= 0) {
+            const float* src = d.rc_logits + ((size_t)g * d.rc_cap + ci) * d.A;
+            for (int i = lane; i < d.A; i += 64) d.root_logits[(size_t)g * d.A + i] = src[i];
+        }
+        __syncthreads();
+        if (lane == 0) { d.root_cached[g] = ci >= 0 ? 1 : 0; d.tree_live[g] = 0; }
     }
 }
 
@@ -360,7 +388,10 @@ __global__ void k_import(Dev d, const int8_t* board, const int8_t* hist, const i
     for (int i = threadIdx.x; i < 8; i += blockDim.x) d.sc[g * 8 + i] = scalars[g * 8 + i];
     for (int i = threadIdx.x; i < d.seen_cap; i += blockDim.x) d.seen[(size_t)g * d.seen_cap + i] = seen[(size_t)g * d.seen_cap + i];
     __syncthreads();
-    if (threadIdx.x == 0) d.hash[g] = hsh;
+    if (threadIdx.x == 0) {
+        d.hash[g] = hsh;
+        if (d.rc_cap) { d.root_cached[g] = 0; d.tree_live[g] = 0; }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -379,6 +410,12 @@ __global__ __launch_bounds__(64) void k_begin(Dev d, const uint8_t* enable) {
     d.child_off[base] = 0; d.n_child[base] = 0;
     d.n_nodes[g] = 1;
     d.n_unique[g] = act ? 1 : 0;  // the root evaluation is the first pending row
+    if (d.rc_cap) {
+        if (act) {
+            for (int i = 0; i < d.rc_cap; ++i) d.rc_valid[(size_t)g * d.rc_cap + i] = 0;
+            d.tree_live[g] = 1;
+        }
+    }
 }
 
 // Exclusive scan of n_unique over games -> row offsets, row->(game, slot) tables, row count.
@@ -387,8 +424,12 @@ __global__ __launch_bounds__(1024) void k_scan_rows(Dev d, int root_phase) {
     const int t = threadIdx.x;
     const int per = (d.G + 1023) / 1024;
     const int lo = min(t * per, d.G), hi = min(lo + per, d.G);
-    int sum = 0;
-    for (int g = lo; g < hi; ++g) sum += d.n_unique[g];
+    const bool split = root_phase && d.rc_cap;   // rows of roots whose logits were carried over go last
+    int sum = 0, late = 0;
+    for (int g = lo; g < hi; ++g) {
+        if (split && d.root_cached[g]) late += d.n_unique[g];
+        else sum += d.n_unique[g];
+    }
     part[t] = sum;
     __syncthreads();
     for (int o = 1; o < 1024; o <<= 1) {
@@ -398,7 +439,9 @@ __global__ __launch_bounds__(1024) void k_scan_rows(Dev d, int root_phase) {
         __syncthreads();
     }
     int off = part[t] - sum;
+    const int n_eval = part[1023];
     for (int g = lo; g < hi; ++g) {
+        if (split && d.root_cached[g]) continue;
         d.row_off[g] = off;
         const int nu = d.n_unique[g];
         for (int u = 0; u < nu; ++u) {
@@ -407,7 +450,27 @@ __global__ __launch_bounds__(1024) void k_scan_rows(Dev d, int root_phase) {
         }
         off += nu;
     }
-    if (t == 1023) { d.row_off[d.G] = part[1023]; d.ctl[0] = part[1023]; }
+    int n_all = n_eval;
+    if (split) {
+        __syncthreads();
+        part[t] = late;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            int v = t >= o ? part[t - o] : 0;
+            __syncthreads();
+            part[t] += v;
+            __syncthreads();
+        }
+        off = n_eval + part[t] - late;
+        for (int g = lo; g < hi; ++g) {
+            if (!d.root_cached[g]) continue;
+            d.row_off[g] = off;
+            for (int u = 0; u < d.n_unique[g]; ++u) { d.row_game[off + u] = g; d.row_slot[off + u] = -1; }
+            off += d.n_unique[g];
+        }
+        n_all = n_eval + part[1023];
+    }
+    if (t == 1023) { d.row_off[d.G] = n_all; d.ctl[0] = n_eval; d.ctl[2] = n_all; }
 }
 
 // (score, index) arg-max over the wave: largest score, smallest index among equals.
@@ -575,7 +638,7 @@ __global__ __launch_bounds__(64) void k_leaf(Dev d, void* out, int layout) {
     uint64_t* seen_lds = (uint64_t*)dyn;
     int8_t* hist_lds = (int8_t*)(dyn + (size_t)d.seen_cap * 8);
     const int r = blockIdx.x, lane = threadIdx.x;
-    if (r >= d.ctl[0]) return;
+    if (r >= d.ctl[2]) return;
     const int g = d.row_game[r], slot = d.row_slot[r];
     Geo<PPL> geo;
     geo_init<PPL>(geo, d.n, lane);
@@ -752,7 +815,8 @@ __global__ __launch_bounds__(64) void k_expand_root(Dev d, const float* logits, 
     const int g = blockIdx.x, lane = threadIdx.x;
     if (!d.active[g]) return;
     const int r = d.row_off[g];
-    expand_node(d, g, lane, 0, logits + (size_t)r * d.A, d.row_legal + (size_t)r * d.A,
+    const float* lg = (d.rc_cap && d.root_cached[g]) ? d.root_logits + (size_t)g * d.A : logits + (size_t)r * d.A;
+    expand_node(d, g, lane, 0, lg, d.row_legal + (size_t)r * d.A,
                 noise ? noise + (size_t)g * d.A : nullptr, p_lds, nullptr, priors_out ? priors_out + (size_t)r * d.A : nullptr);
 }
 
@@ -770,6 +834,14 @@ __global__ __launch_bounds__(64) void k_expand_backup(Dev d, const float* logits
         const int node = path[d.path_len[g * d.B + slot] - 1];
         expand_node(d, g, lane, node, logits + (size_t)(r0 + u) * d.A, d.row_legal + (size_t)(r0 + u) * d.A, nullptr, p_lds,
                     nullptr, priors_out ? priors_out + (size_t)(r0 + u) * d.A : nullptr);
+        if (d.rc_cap && d.path_len[g * d.B + slot] == 2) {   // a child of the root: a candidate for the next root
+            const int ci = node - d.child_off[(size_t)g * d.max_nodes];
+            if (ci >= 0 && ci < d.rc_cap) {
+                float* dst = d.rc_logits + ((size_t)g * d.rc_cap + ci) * d.A;
+                for (int i = lane; i < d.A; i += 64) dst[i] = logits[(size_t)(r0 + u) * d.A + i];
+                if (lane == 0) d.rc_valid[(size_t)g * d.rc_cap + ci] = 1;
+            }
+        }
     }
     const size_t nb = (size_t)g * d.max_nodes;
     double* vsum = d.vsum + nb;
@@ -853,6 +925,7 @@ struct az_engine {
     int phase = PH_IDLE;
     int sims_done = 0, batch_n = 0;
     int pending_rows = 0;
+    int gather_rows = 0;            // rows az_mcts_gather fills (pending_rows + roots whose logits were carried over)
     bool rows_known = false;
     bool async_mode = false;        // never synchronise inside a search: grids sized by upper bounds
     int* ctl_host = nullptr;        // pinned
@@ -1059,10 +1132,42 @@ int az_mcts_pending(az_engine* e, int32_t* rows_out, void* stream) {
     HIP_TRY(hipMemcpyAsync(e->ctl_host, e->d.ctl, 4 * sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     e->pending_rows = e->ctl_host[0];
+    e->gather_rows = e->ctl_host[2];
     e->rows_known = true;
     *rows_out = e->pending_rows;
     if (e->ctl_host[1] == AZ_ERR_NOCHILD) return fail(AZ_ERR_NOCHILD, "No child selected in MCTS");
     if (e->ctl_host[1] == AZ_ERR_CAPACITY) return fail(AZ_ERR_CAPACITY, "search tree node capacity exceeded");
+    return AZ_OK;
+}
+
+static int need_rows(az_engine* e, void* stream);
+
+int az_mcts_gather_rows(az_engine* e, int32_t* rows_out, void* stream) {
+    if (!e || !rows_out) return fail(AZ_ERR_ARG, "null argument");
+    if (e->phase != PH_ROOT && e->phase != PH_SELECTED) { *rows_out = 0; return AZ_OK; }
+    int rc = need_rows(e, stream);
+    if (rc != AZ_OK) return rc;
+    *rows_out = e->gather_rows;
+    return AZ_OK;
+}
+
+int az_mcts_set_root_reuse(az_engine* e, int32_t enable) {
+    if (!e) return fail(AZ_ERR_ARG, "null engine");
+    Dev& d = e->d;
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    HIP_TRY(hipDeviceSynchronize());
+    if (!enable) { d.rc_cap = 0; return AZ_OK; }
+    const int cap = d.K > 0 ? std::min(d.K, d.A) : d.A;
+    if ((size_t)d.G * cap * d.A * 4 > ((size_t)1 << 30)) return fail(AZ_ERR_CAPACITY, "root reuse: logits store above 1 GiB");
+    if (!d.rc_logits) {
+        if (dev_alloc(e, &d.rc_logits, (size_t)d.G * cap * d.A) || dev_alloc(e, &d.rc_valid, (size_t)d.G * cap) ||
+            dev_alloc(e, &d.root_logits, (size_t)d.G * d.A) || dev_alloc(e, &d.root_cached, (size_t)d.G) || dev_alloc(e, &d.tree_live, (size_t)d.G))
+            return AZ_ERR_HIP;
+    }
+    HIP_TRY(hipMemset(d.root_cached, 0, d.G));
+    HIP_TRY(hipMemset(d.tree_live, 0, d.G));
+    HIP_TRY(hipMemset(d.rc_valid, 0, (size_t)d.G * cap));
+    d.rc_cap = cap;
     return AZ_OK;
 }
 
@@ -1094,7 +1199,7 @@ int az_mcts_gather(az_engine* e, void* out, int32_t layout, void* stream) {
     } else {
         int rc = need_rows(e, stream);
         if (rc != AZ_OK) return rc;
-        grid = e->pending_rows;
+        grid = e->gather_rows;
     }
     if (grid == 0) return AZ_OK;
     const size_t shmem = seen_bytes(e) + (size_t)e->d.H * e->d.npad;
@@ -1114,7 +1219,7 @@ int az_mcts_expand(az_engine* e, const float* logits, const float* values, const
     if (!e) return fail(AZ_ERR_ARG, "null engine");
     const size_t shmem = (size_t)e->d.A * 8 + 64;
     if (e->phase == PH_ROOT) {
-        if (!logits) return fail(AZ_ERR_ARG, "null logits");
+        if (!logits && !(e->d.rc_cap && e->rows_known && e->pending_rows == 0)) return fail(AZ_ERR_ARG, "null logits");
         hipLaunchKernelGGL(k_expand_root, dim3(e->d.G), dim3(64), shmem, (hipStream_t)stream, e->d, logits, noise, e->last_priors);
     } else if (e->phase == PH_SELECTED) {
         if (!e->async_mode) {

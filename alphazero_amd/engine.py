@@ -132,6 +132,16 @@ class Engine:
         N.check(self.L.az_mcts_pending(self._h, C.byref(r), _stream()), "az_mcts_pending")
         return r.value
 
+    def set_root_reuse(self, enable: bool):
+        """Carry the logits of the played child over to the next search's root (see az_mcts_set_root_reuse)."""
+        with torch.cuda.device(self.device):
+            N.check(self.L.az_mcts_set_root_reuse(self._h, 1 if enable else 0), "az_mcts_set_root_reuse")
+
+    def gather_rows(self) -> int:
+        r = C.c_int32()
+        N.check(self.L.az_mcts_gather_rows(self._h, C.byref(r), _stream()), "az_mcts_gather_rows")
+        return r.value
+
     def set_async(self, enable: bool):
         """Asynchronous mode: gather/expand never wait for the device (see az_mcts_set_async)."""
         N.check(self.L.az_mcts_set_async(self._h, 1 if enable else 0), "az_mcts_set_async")

@@ -169,6 +169,11 @@ class _Lane:
                 self.feat_buf = torch.empty((self.max_rows, cfg.board_size ** 2, self.eng.cpad), dtype=torch.bfloat16, device=self.dev)
             else:
                 self.feat_buf = torch.empty((self.max_rows, self.eng.Cp, cfg.board_size, cfg.board_size), dtype=torch.float32, device=self.dev)
+            # the native bf16 network gives a position the same output in any batch, so the logits of the child that is
+            # played can stand in for the evaluation of the next root
+            self.root_reuse = self.net is not None and precision == "bf16" and owner.reuse_roots
+            if self.root_reuse:
+                self.eng.set_root_reuse(True)
             # with the native bf16 network the batches of a search are enqueued without host round trips
             self.async_search = self.net is not None and precision == "bf16" and self.net.fused
             if self.async_search:
@@ -239,10 +244,10 @@ class _Lane:
             eng.search_begin(torch.from_numpy(active.astype(np.uint8)))
             rows = eng.pending()
             to_play = info.cpu().numpy()[:, 0].copy()
-            if rows == 0:
-                raise N.NativeError("search with no root to evaluate")
+            if eng.gather_rows() == 0:
+                raise N.NativeError("search with no root")
             feats = eng.gather(rows, self.layout, out=self.feat_buf)
-            logits, values = self.eval(feats[:rows])
+            logits, values = self.eval(feats[:rows]) if rows > 0 else (None, None)   # rows == 0: every root's logits were carried over
             counts = eng.root_legal_counts().cpu().numpy()
             t0 = time.perf_counter()
             noise = self.rng.dirichlet(counts, cfg.dirichlet_alpha, self.A)
@@ -364,8 +369,9 @@ class BatchedSelfPlay:
 
     def __init__(self, model, cfg: SelfPlayConfig, games: int, seed0: int = 0, dedup_leaves: bool = True,
                  precision: str = "bf16", collect_samples: bool = True, device=None, rng_threads: int = 8,
-                 lanes: int = 1, tower_workgroups: int | None = None):
+                 lanes: int = 1, tower_workgroups: int | None = None, reuse_roots: bool = True):
         self.cfg, self.G, self.seed0 = cfg, int(games), int(seed0)
+        self.reuse_roots = bool(reuse_roots)
         self.collect = collect_samples
         self.dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         lanes = max(1, min(int(lanes), self.G))

@@ -103,6 +103,15 @@ int az_mcts_select(az_engine* e, void* stream);
 /* Number of pending rows. Synchronises `stream`. Also reports and clears per-game failures
  * (returns AZ_ERR_NOCHILD / AZ_ERR_CAPACITY). */
 int az_mcts_pending(az_engine* e, int32_t* rows_out, void* stream);
+/* Root-evaluation reuse (enable != 0), for evaluators that are pure functions of a position independent of the
+ * batch it is in (az_net_forward is; a framework model on the host need not be): the state a game is in after
+ * az_rules_play was evaluated as a child of the previous root, so its logits are carried over and the next
+ * az_mcts_begin asks for no evaluation of that root. az_mcts_pending then counts only the rows to evaluate;
+ * az_mcts_gather still fills az_mcts_gather_rows rows (the carried-over roots last: their legal masks are needed),
+ * and az_mcts_expand takes logits for the first az_mcts_pending rows (NULL if there are none). Off by default.
+ * Use one evaluator per engine while it is on. Synchronises the device. */
+int az_mcts_set_root_reuse(az_engine* e, int32_t enable);
+int az_mcts_gather_rows(az_engine* e, int32_t* rows_out, void* stream);
 /* Asynchronous mode (enable != 0): az_mcts_gather and az_mcts_expand never synchronise; launches are
  * sized by upper bounds (G rows for the roots, az_engine_max_rows for a batch) and surplus workers
  * exit on the device-side row count, so a whole search can be enqueued without host round trips.

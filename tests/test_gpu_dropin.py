@@ -119,14 +119,15 @@ def test_lockstep_selfplay_reproduces_upstream_game(name, slots):
     del want_actions
 
 
-def _small_selfplay(lanes, use_async, games=6, num_games=9, steps=None):
+def _small_selfplay(lanes, use_async, games=6, num_games=9, steps=None, reuse_roots=True):
     import torch
     from alphazero_amd.model import AlphaZeroNet
     from alphazero_amd.selfplay import BatchedSelfPlay, SelfPlayConfig
     torch.manual_seed(3)
     net = AlphaZeroNet(board_size=5, channels=32, num_blocks=2).eval().cuda()
     cfg = SelfPlayConfig(board_size=5, mcts_simulations=24, mcts_inference_batch=4, mcts_topk_expand=6)
-    sp = BatchedSelfPlay(net, cfg, games=games, seed0=11, lanes=lanes, tower_workgroups=None if lanes == 1 else 1024)
+    sp = BatchedSelfPlay(net, cfg, games=games, seed0=11, lanes=lanes, tower_workgroups=None if lanes == 1 else 1024,
+                         reuse_roots=reuse_roots)
     assert sp.async_search
     sp.set_async(use_async)
     assert sp.async_search == use_async
@@ -241,3 +242,22 @@ def test_full_length_selfplay_config2():
     assert set(np.unique(zs)) <= {-1.0, 0.0, 1.0}
     st = sp.eng.stats()
     assert st["max_nodes"] <= 1 + 193 * 24 and st["max_depth"] <= 164
+
+
+@pytest.mark.parametrize("use_async", [True, False])
+def test_root_reuse_plays_the_same_games_with_fewer_evaluations(use_async):
+    """The logits of the child that gets played stand in for the evaluation of the next root (the network gives a
+    position the same output in any batch): same games, one network row less per move after a game's first."""
+    a = _small_selfplay(1, use_async, reuse_roots=True)
+    b = _small_selfplay(1, use_async, reuse_roots=False)
+    assert sorted(a.finished) == sorted(b.finished) == list(range(9)) and a.results == b.results
+    for gid in range(9):
+        ta, wa = a.trajectory(gid)
+        tb, wb = b.trajectory(gid)
+        assert wa == wb and len(ta) == len(tb)
+        for ma, mb in zip(ta, tb):
+            for xa, xb in zip(ma, mb):
+                assert np.array_equal(xa, xb)
+    assert a.counters["moves"] == b.counters["moves"]
+    saved = b.counters["nn_rows"] - a.counters["nn_rows"]
+    assert saved == a.counters["moves"] - 9          # every move but the first of each of the 9 games
