@@ -184,7 +184,7 @@ def main():
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic (random-init weights, games from the empty board)",
         "config": {"workload": "9x9 full net 192ch x 12 SE blocks, 256 sims/move, top-k 48, virtual loss 1.0, "
                                f"{a.games} lockstep games per GPU (BASELINE.json configs[2])",
-                   "games_per_gpu": a.games, "lanes": a.lanes, "inference_batch": a.batch, "dedup_repeated_leaves": not a.no_dedup,
+                   "games_per_gpu": a.games, "lanes": a.lanes, "inference_batch": a.batch, "dedup_repeated_leaves": not a.no_dedup, "root_evaluation_reuse": True,
                    "parallelism": f"games sharded over {world} GPU(s), no data-path collective"},
         "sims_per_s": round(sims / dt_max, 1),
         "nn_rows_per_s": round(rows / dt_max, 1),
