@@ -391,11 +391,19 @@ static inline uint16_t f2bf(float f) {
 // l & 15 of the tile and input channels 8*(l >> 4).. of the k-step. Tile rows are assigned to output
 // channels so that the MFMA result gives a lane 8 consecutive channels over the tile pair (2p, 2p+1):
 // row r of tile 2p+e is channel 32*p + 8*(r >> 2) + 4*e + (r & 3).
-static inline std::vector<uint16_t> pack_conv(const std::vector<float>& w, int cout, int cin, int taps, int cin_pad, int ncols) {
+// channel_major: the k-steps run over 64-channel chunks first and over the taps inside a chunk (k-step
+// (chunk*taps + tap)*2 + half) instead of tap after tap; cin_pad must then be a multiple of 64.
+static inline std::vector<uint16_t> pack_conv(const std::vector<float>& w, int cout, int cin, int taps, int cin_pad, int ncols,
+                                              bool channel_major = false) {
     const int kpt = cin_pad / 32, nks = (taps * kpt + 1) & ~1, ntile = ncols / 16;
     std::vector<uint16_t> out((size_t)nks * ntile * 64 * 8, 0);
     for (int s = 0; s < nks; ++s) {
-        const int tap = s / kpt, c0 = (s % kpt) * 32;
+        int tap = s / kpt, c0 = (s % kpt) * 32;
+        if (channel_major) {
+            const int tile = s >> 1;
+            tap = tile % taps;
+            c0 = (tile / taps) * 64 + (s & 1) * 32;
+        }
         if (tap >= taps) continue;
         for (int nt = 0; nt < ntile; ++nt)
             for (int l = 0; l < 64; ++l) {

@@ -1,8 +1,8 @@
 // bf16 MFMA inference of the policy/value tower (model.py:43-97, eval mode) layer by layer, for the shapes
-// whose activations do not fit one workgroup's LDS (boards above 9x9, 256 channels): every 3x3 / 1x1
-// convolution is one launch of k_conv_layer, an implicit GEMM over all boards of a chunk with the same
-// v_mfma_f32_16x16x32_bf16 tile loop as the fused tower (az_mfma_gemm.cuh) -- weight tiles double-buffered in
-// LDS, activation fragments read straight from the bf16 [position][channel] arrays in HBM/L2. The
+// whose activations do not fit one workgroup's LDS (boards above 9x9, 256 channels): every convolution is one
+// launch, an implicit GEMM over all boards of a chunk on v_mfma_f32_16x16x32_bf16 with the weight tiles
+// double-buffered in LDS like in the fused tower (az_mfma_gemm.cuh). The 3x3 convolutions (k_conv3_slab) stage
+// the bf16 [position][channel] activations through LDS slabs; the 1x1 head (k_conv_layer) reads them from L2. The
 // squeeze-excite gate (pooled in position order, so a board's result does not depend on its neighbours in the
 // batch) and the residual add are two small bandwidth-bound kernels between the convolutions.
 #include <hip/hip_runtime.h>
@@ -50,6 +50,177 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_conv_layer(Conv
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
             const int row = g.row0 + row_base + mi * 16 + lr;
+            float v[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { v[r] = acc[mi][2 * p][r] + bv[r]; v[4 + r] = acc[mi][2 * p + 1][r] + bv[4 + r]; }
+            if (a.relu) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
+            if (row < a.rows)
+                *(uint4*)(a.out + (size_t)row * a.out_stride + (size_t)(cbase + 32 * p) * 2) =
+                    make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
+        }
+    }
+}
+
+// 3x3 convolution with the activations staged through LDS: the workgroup's 256 rows plus a halo of n+1 rows
+// on either side, 64 input channels at a time ("slab", row stride 160 B: conflict-free 16-byte fragment reads),
+// double-buffered; the nine taps of a channel chunk read the same slab at shifted rows, so every activation
+// byte is fetched from L2 once per chunk instead of nine times. K order: chunk-major (pack_conv channel_major).
+// Slab kc+1 is fetched global -> registers -> LDS one 16-byte piece per thread and tile while chunk kc computes.
+constexpr int kSlabStride = 160, kMaxHalo = 20, kSlabRows = 256 + 2 * kMaxHalo, kSlabBytes = kSlabRows * kSlabStride;
+constexpr int kSlabPieces = (kSlabRows * 8 + 511) / 512;   // 16-byte pieces per thread of a 512-thread workgroup
+
+template <int NCOLS, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_conv3_slab(ConvArgs a) {
+    constexpr int NW = WM * WN, NT = 64 * NW;
+    constexpr int MI = 256 / (WM * 16), NI = NCOLS / (WN * 16);
+    constexpr int tile_bytes = 64 * NCOLS * 2, nvec = tile_bytes / 16, kstep_bytes = tile_bytes / 2;
+    constexpr int NCHUNK = nvec / 64, PW = (NCHUNK + NW - 1) / NW;
+    constexpr bool RAGGED = (NCHUNK % NW) != 0;
+    static_assert(NI % 2 == 0 && NT == 512, "tile pairs; slab pieces are dealt to 512 threads");
+    extern __shared__ __attribute__((aligned(256))) char smem[];
+    char* slab = smem;                         // two slabs
+    char* zreg = smem + 2 * kSlabBytes;        // 1 KiB of zeros, 256-byte aligned (kSlabBytes is a multiple of 256)
+    char* bbuf = zreg + 1024;                  // two weight tiles
+    AZ_LANE_GEO(MI, NI, WN);
+    const int n = a.n, np = a.np, halo = n + 1, srows = 256 + 2 * halo;
+    const int row0 = blockIdx.x * 256, C2 = a.in_stride, nkc = a.in_stride / 128, ntiles = nkc * 9;
+    const uint4* wg = a.w + (size_t)blockIdx.y * a.w_block_vecs;
+    for (int i = t_; i < 256; i += NT) ((uint32_t*)zreg)[i] = 0;
+    stage_tile<NW>(wg, bbuf, nvec, lane, wave);
+    stage_tile<NW>(wg + nvec, bbuf + tile_bytes, nvec, lane, wave);
+    uint4 stg[PW];
+    const uint4* wsrc = wg + lane + wave * 64;
+#pragma unroll
+    for (int i = 0; i < PW; ++i) {
+        stg[i] = make_uint4(0, 0, 0, 0);
+        if (!RAGGED || wave + i * NW < NCHUNK) stg[i] = wsrc[(size_t)2 * nvec + i * NW * 64];
+    }
+    // this thread's slab pieces: piece j = t_ + i*NT -> slab row j >> 3, 16-byte part j & 7 (recomputed where used:
+    // holding the offsets would cost registers the accumulators need)
+    auto piece = [&](int i, int& src, int& dst) {
+        const int j = opaque(t_) + i * NT, srow = j >> 3, part = j & 7, grow = row0 - halo + srow;
+        dst = srow < srows ? srow * kSlabStride + part * 16 : -1;
+        src = (srow < srows && grow >= 0 && grow < a.rows) ? grow * C2 + part * 16 : -1;   // -1: outside the array, zeros
+    };
+#pragma unroll
+    for (int i = 0; i < kSlabPieces; ++i) {   // slab 0
+        int src, dst;
+        piece(i, src, dst);
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (src >= 0) v = *(const uint4*)(a.in + src);
+        if (dst >= 0) *(uint4*)(slab + dst) = v;
+    }
+    uint4 sp = make_uint4(0, 0, 0, 0);   // the piece of the next slab in flight
+    // fragment geometry
+    int roff[MI], vmask[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int lrow = row_base + mi * 16 + lr, row = row0 + lrow;
+        const int p = row % np, y = p / n, x = p - y * n;
+        int m = 0;
+        if (row < a.rows) {
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) {
+                const int yy = y + tp / 3 - 1, xx = x + tp % 3 - 1;
+                if ((unsigned)yy < (unsigned)n && (unsigned)xx < (unsigned)n) m |= 1 << tp;
+            }
+        }
+        vmask[mi] = m;
+        roff[mi] = (lrow + halo) * kSlabStride + kq * 16;
+    }
+    const int zbase = 2 * kSlabBytes;   // offset of the zero region from `slab`
+    const int woff = ((wn * NI) * 64 + lane) * 16, soff = (wave * 64 + lane) * 16;
+    auto tap_offsets = [&](int (&out)[MI], int tap, int sbase) {
+        const int shift = ((tap / 3 - 1) * n + (tap - (tap / 3) * 3 - 1)) * kSlabStride + sbase;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int reg = roff[mi] + shift;
+            out[mi] = (vmask[mi] >> tap & 1) ? reg : zbase + (reg & 255);
+        }
+    };
+    f32x4 acc[MI][NI];
+    zero_acc<MI, NI>(acc);
+    int apc[MI], apn[MI];
+    tap_offsets(apc, 0, 0);
+    if (ntiles > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    bf16x8 a0[MI], b0[NI], a1[MI], b1[NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) a0[mi] = *(const bf16x8*)(slab + apc[mi]);
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) b0[ni] = *(const bf16x8*)(bbuf + woff + ni * 1024);
+    int t = 0;
+    for (int kc = 0; kc < nkc; ++kc) {
+        const int sb_cur = (kc & 1) * kSlabBytes, sb_nxt = kSlabBytes - sb_cur;
+        const bool more = kc + 1 < nkc;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap, ++t) {
+            const int par = (t & 1) * tile_bytes;
+            char* X = bbuf + par;
+            const char* Y = bbuf + (tile_bytes - par);
+            // fragment offsets of the next tile: next tap in this slab, or tap 0 of the next chunk's slab
+            if (tap < 8) tap_offsets(apn, tap + 1, sb_cur);
+            else tap_offsets(apn, 0, sb_nxt);
+            // ---- first k-step
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) a1[mi] = *(const bf16x8*)(slab + apc[mi] + 64);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) b1[ni] = *(const bf16x8*)(X + kstep_bytes + woff + ni * 1024);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[ni], a0[mi], acc[mi][ni], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+            {   // weight tile t+2 -> X, fetch tile t+3
+                const uint4* src = wsrc + (size_t)min(t + 3, ntiles - 1) * nvec;
+#pragma unroll
+                for (int i = 0; i < PW; ++i)
+                    if (!RAGGED || wave + i * NW < NCHUNK) {
+                        *(uint4*)(X + soff + i * NW * 1024) = stg[i];
+                        stg[i] = src[i * NW * 64];
+                    }
+            }
+            // next slab: piece `tap` is fetched during tile `tap` and stored during tile tap+1 (tiles 0..kSlabPieces)
+            if (more) {
+                int src, dst;
+                if (tap >= 1 && tap <= kSlabPieces) {
+                    piece(tap - 1, src, dst);
+                    if (dst >= 0) *(uint4*)(slab + sb_nxt + dst) = sp;
+                }
+                if (tap < kSlabPieces) {
+                    piece(tap, src, dst);
+                    sp = make_uint4(0, 0, 0, 0);
+                    if (src >= 0) sp = *(const uint4*)(a.in + src + (kc + 1) * 128);
+                }
+            }
+            // ---- second k-step
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) a0[mi] = *(const bf16x8*)(slab + apn[mi]);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) b0[ni] = *(const bf16x8*)(Y + woff + ni * 1024);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[ni], a1[mi], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) apc[mi] = apn[mi];
+        }
+    }
+    // epilogue: bias, ReLU, bf16 rows to global memory
+    const int cbase = blockIdx.y * NCOLS + col0 + 8 * kq;
+#pragma unroll
+    for (int p = 0; p < NI / 2; ++p) {
+        const float4 x0 = *(const float4*)(a.bias + cbase + 32 * p), x1 = *(const float4*)(a.bias + cbase + 32 * p + 4);
+        const float bv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int row = row0 + row_base + mi * 16 + lr;
             float v[8];
 #pragma unroll
             for (int r = 0; r < 4; ++r) { v[r] = acc[mi][2 * p][r] + bv[r]; v[4 + r] = acc[mi][2 * p + 1][r] + bv[4 + r]; }
@@ -130,6 +301,7 @@ struct PackedConv {
     float* b = nullptr;
     size_t block_vecs = 0;
     int cin_pad = 0, cout = 0, ncols = 0, taps = 0;
+    bool slab = false;   // 3x3 with activations staged through LDS (weights packed chunk-major)
 };
 
 struct LayerNet {
@@ -159,12 +331,13 @@ static int dev_up(LayerNet* m, const T* src, size_t count, T** out) {
 // Folded weights w[cout][cin][taps] -> one packed run per block of `ncols` output channels.
 static int pack_layer(LayerNet* m, const std::vector<float>& w, const std::vector<float>& b, int cout, int cin, int taps, int cin_pad,
                       int ncols, PackedConv* out) {
+    const bool slab = taps == 9 && cin_pad % 64 == 0;
     std::vector<uint16_t> all;
     size_t block = 0;
     for (int c0 = 0; c0 < cout; c0 += ncols) {
         const int nc = std::min(ncols, cout - c0);
         std::vector<float> sub(w.begin() + (size_t)c0 * cin * taps, w.begin() + (size_t)(c0 + nc) * cin * taps);
-        std::vector<uint16_t> pk = pack_conv(sub, nc, cin, taps, cin_pad, ncols);
+        std::vector<uint16_t> pk = pack_conv(sub, nc, cin, taps, cin_pad, ncols, slab);
         block = pk.size() * 2 / 16;
         all.insert(all.end(), pk.begin(), pk.end());
     }
@@ -176,6 +349,7 @@ static int pack_layer(LayerNet* m, const std::vector<float>& w, const std::vecto
     rc = dev_up(m, bias.data(), bias.size(), &out->b);
     if (rc != AZ_OK) return rc;
     out->w = (uint4*)wd; out->block_vecs = block; out->cin_pad = cin_pad; out->cout = cout; out->ncols = ncols; out->taps = taps;
+    out->slab = slab;
     return AZ_OK;
 }
 
@@ -265,6 +439,20 @@ static void launch_one(const ConvArgs& a, int cout, hipStream_t st) {
     hipLaunchKernelGGL((k_conv_layer<KPT, NCOLS, WM, WN>), grid, dim3(64 * WM * WN), (size_t)2 * 64 * NCOLS * 2, st, a);
 }
 
+template <int NCOLS>
+static int launch_slab(const ConvArgs& a, int cout, hipStream_t st) {
+    const size_t lds = (size_t)2 * kSlabBytes + 1024 + (size_t)2 * 64 * NCOLS * 2;
+    static bool opted = false;   // the large dynamic LDS size is opted into once per kernel
+    if (!opted) {
+        if (hipFuncSetAttribute((const void*)k_conv3_slab<NCOLS, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return fail(AZ_ERR_HIP, "hipFuncSetAttribute (k_conv3_slab)");
+        opted = true;
+    }
+    const dim3 grid((a.rows + 255) / 256, (cout + NCOLS - 1) / NCOLS);
+    hipLaunchKernelGGL((k_conv3_slab<NCOLS, 4, 2>), grid, dim3(512), lds, st, a);
+    return AZ_OK;
+}
+
 // Tower convolutions: 4x2 waves of 64 positions x NCOLS/2 channels. Heads: 8x1 waves of 32 positions x all channels.
 static int launch_conv(const PackedConv& pc, const char* in, int zero_off, char* out, int out_stride, int rows, int n, int relu, bool head,
                        hipStream_t st) {
@@ -272,6 +460,14 @@ static int launch_conv(const PackedConv& pc, const char* in, int zero_off, char*
     a.in = in; a.in_stride = pc.cin_pad * 2; a.zero_off = zero_off; a.w = pc.w; a.w_block_vecs = pc.block_vecs; a.bias = pc.b;
     a.out = out; a.out_stride = out_stride; a.rows = rows; a.n = n; a.np = n * n; a.ntaps = pc.taps; a.relu = relu;
     const int key = (pc.cin_pad / 32) * 1000 + pc.ncols;
+    if (pc.slab && n + 1 <= kMaxHalo) {
+        switch (pc.ncols) {
+            case 64: return launch_slab<64>(a, pc.cout, st);
+            case 128: return launch_slab<128>(a, pc.cout, st);
+            case 192: return launch_slab<192>(a, pc.cout, st);
+            default: return fail(AZ_ERR_ARG, "bf16 layer path: no slab kernel for this shape");
+        }
+    }
     if (!head) {
         switch (key) {
             case 2064: launch_one<2, 64, 4, 2>(a, pc.cout, st); break;     // stem or 64-channel tower
