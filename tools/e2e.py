@@ -1,28 +1,35 @@
-"""Quick end-to-end lockstep self-play timing (development aid)."""
-import sys, time
+"""Quick end-to-end lockstep self-play timing (development aid).
+
+  python tools/e2e.py GAMES STEPS [DEDUP] [B] [BOARD] [CHANNELS] [BLOCKS] [SIMS] [TOPK] [LANES]
+"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from alphazero_amd.model import AlphaZeroNet
 from alphazero_amd.selfplay import BatchedSelfPlay, SelfPlayConfig
 
-G = int(sys.argv[1]) if len(sys.argv) > 1 else 512
-steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-dedup = (sys.argv[3] != "0") if len(sys.argv) > 3 else True
-B = int(sys.argv[4]) if len(sys.argv) > 4 else 16
+arg = lambda i, d: type(d)(sys.argv[i]) if len(sys.argv) > i else d
+G, steps, dedup, B = arg(1, 512), arg(2, 3), arg(3, 1) != 0, arg(4, 16)
+n, ch, blocks, sims, topk, lanes = arg(5, 9), arg(6, 192), arg(7, 12), arg(8, 256), arg(9, 48), arg(10, 1)
 torch.manual_seed(0)
-net = AlphaZeroNet().eval().to("cuda:0")
-cfg = SelfPlayConfig(mcts_simulations=256, mcts_inference_batch=B, mcts_topk_expand=48)
-sp = BatchedSelfPlay(net, cfg, games=G, seed0=1, dedup_leaves=dedup)
-sp.run(max_steps=1)
+net = AlphaZeroNet(board_size=n, channels=ch, num_blocks=blocks).eval().to("cuda:0")
+cfg = SelfPlayConfig(board_size=n, mcts_simulations=sims, mcts_inference_batch=B, mcts_topk_expand=topk)
+sp = BatchedSelfPlay(net, cfg, games=G, seed0=1, dedup_leaves=dedup, lanes=lanes, tower_workgroups=1024 if lanes > 1 else None)
+sp.begin(num_games=10 ** 9)
+for _ in range(2):
+    sp.step()
 torch.cuda.synchronize()
-for k in sp.counters: sp.counters[k] = 0
-sp.net.profile(True)
+for k in sp.counters:
+    sp.counters[k] = 0
 t = time.time()
-sp.run(max_steps=steps)
+for _ in range(steps):
+    sp.step()
 torch.cuda.synchronize()
 dt = time.time() - t
 c = sp.counters
-ms, ln, rw = sp.net.profile(False, read=True)
-print(f"G={G} steps={steps} dedup={dedup} B={B}: {dt:.2f}s  sims/s={c['sims']/dt:.0f} nn_rows/s={c['nn_rows']/dt:.0f} "
-      f"rows_nodedup={c['nn_rows_nodedup']} rows={c['nn_rows']} tower_ms={ms:.1f} ({ms/dt/10:.1f}% of wall) launches={ln} "
-      f"host_rng={c['t_host_rng']:.3f}s host_policy={c['t_host_policy']:.3f}s samples={c['t_samples']:.3f}s "
-      f"mean_depth={c['depth_sum']/max(1,c['sims']):.2f}")
+print(f"board={n} net={ch}x{blocks} G={G} sims={sims} B={B} K={topk} lanes={lanes} dedup={dedup} fused={sp.net.fused} async={sp.async_search}: "
+      f"{dt / steps * 1e3:.1f} ms/step, sims/s={c['sims'] / dt:.0f}, nn_rows/s={c['nn_rows'] / dt:.0f}, "
+      f"mean_depth={c['depth_sum'] / max(1, c['sims']):.2f}, host rng/policy/samples={c['t_host_rng']:.3f}/{c['t_host_policy']:.3f}/{c['t_samples']:.3f}s")
