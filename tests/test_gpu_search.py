@@ -94,3 +94,32 @@ def test_terminal_and_masked_roots_sit_out():
     v = visits.cpu().numpy()
     assert v[0].sum() == 0 and v[2].sum() == 0 and v[1].sum() == 8
     eng.close()
+
+
+def test_full_size_search_dedup_invariance():
+    """BASELINE configs[2] at full size (4096 games, 192ch x 12 net, 256 sims, top-k 48, B 16), one search from
+    positions a few random plies in: evaluating a repeated leaf once or every time gives the same visit counts and
+    root values, every game's visits add up to the simulation count, and the every-leaf run evaluates
+    games x simulations leaves."""
+    import torch
+    from alphazero_amd.engine import Engine
+    from alphazero_amd.model import AlphaZeroNet
+    torch.manual_seed(0)
+    net = AlphaZeroNet(channels=192, num_blocks=12).eval().cuda().native("bf16")
+    G, out = 4096, []
+    rng = np.random.RandomState(3)
+    plies = [rng.randint(0, 81, size=G).astype(np.int32) for _ in range(4)]
+    for dedup in (True, False):
+        eng = Engine(board_size=9, games=G, num_simulations=256, inference_batch_size=16, topk_expand=48, dedup_leaves=dedup)
+        for a in plies:
+            eng.play(a, raise_on_illegal=False)          # occupied points are skipped, the same way in both runs
+        noise_rngs = [np.random.RandomState(100 + g) for g in range(G)]
+        visits, rv = eng.run_search(net.forward, add_noise=True, rngs=noise_rngs, layout=net.layout)
+        st = eng.stats()
+        out.append((visits.cpu().numpy(), rv.cpu().numpy(), st))
+        eng.close()
+    (va, ra, sa), (vb, rb, sb) = out
+    assert np.array_equal(va, vb) and np.array_equal(ra, rb)
+    assert (va.sum(axis=1) == 256).all()
+    assert sa["sims"] == sb["sims"] == G * 256 and sb["rows"] == sb["rows_raw"] == G * 256 - sb["terminal"]
+    assert sa["rows"] < sb["rows"] and sa["rows_raw"] == sb["rows_raw"]
