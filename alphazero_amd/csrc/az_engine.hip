@@ -925,6 +925,7 @@ struct az_engine {
     int phase = PH_IDLE;
     int sims_done = 0, batch_n = 0;
     int pending_rows = 0;
+    int last_rows = -1;             // rows the last az_mcts_expand produced priors for (-1: not known on the host)
     int gather_rows = 0;            // rows az_mcts_gather fills (pending_rows + roots whose logits were carried over)
     bool rows_known = false;
     bool async_mode = false;        // never synchronise inside a search: grids sized by upper bounds
@@ -1237,6 +1238,7 @@ int az_mcts_expand(az_engine* e, const float* logits, const float* values, const
     }
     int rc = check_launch("k_expand");
     if (rc != AZ_OK) return rc;
+    e->last_rows = e->rows_known ? e->gather_rows : -1;
     e->rows_known = false;
     if (e->sims_done >= e->d.sims) { e->phase = PH_DONE; return 1; }
     e->phase = PH_NEED_SELECT;
@@ -1258,7 +1260,8 @@ int az_mcts_result(az_engine* e, int32_t* visits, double* root_value, void* stre
 
 int az_mcts_last_priors(az_engine* e, double* priors, void* stream) {
     if (!e || !priors) return fail(AZ_ERR_ARG, "null argument");
-    HIP_TRY(hipMemcpyAsync(priors, e->last_priors, (size_t)e->pending_rows * e->d.A * 8, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    if (e->last_rows < 0) return fail(AZ_ERR_STATE, "az_mcts_last_priors: the row count of the last expansion was never read (asynchronous mode)");
+    HIP_TRY(hipMemcpyAsync(priors, e->last_priors, (size_t)e->last_rows * e->d.A * 8, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return AZ_OK;
 }
 
