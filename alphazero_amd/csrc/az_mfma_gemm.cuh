@@ -368,6 +368,84 @@ __device__ __forceinline__ void gemm_conv(f32x4 (&acc)[MI][NI], const uint4* __r
     }
 }
 
+// The same convolution with the weight fragments read straight from the packed global image into registers (the
+// image is stored in fragment order, so a fragment is one coalesced 1 KiB load; the waves that share output channels
+// hit the same lines in the CU's vector cache). Nothing is staged through LDS and the activations are read-only
+// during the loop, so there is no workgroup barrier inside: every wave runs its MFMAs at its own pace, with the
+// weight fragments of the next DEPTH k-steps in flight.
+template <int MI, int NI, int WM, int WN, int NCOLS, int KPT, int DEPTH>
+__device__ __forceinline__ void gemm_conv_gw(f32x4 (&acc)[MI][NI], const uint4* __restrict__ wg, int ntaps, bool three, const char* act,
+                                             int in_stride, const char* zrow, const TileGeo& g) {
+    AZ_LANE_GEO(MI, NI, WN);
+    const int nks = ntaps * KPT;
+    int roff[MI], vmask[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int row = row_base + mi * 16 + lr;
+        const int p = row - (int)((row * g.recip_np) >> 16) * g.np;
+        const int y = (p * g.recip_n) >> 16, x = p - y * g.n;
+        int m = 0;
+        if (row < g.vrows) {
+            if (three) {
+#pragma unroll
+                for (int tp = 0; tp < 9; ++tp) {
+                    const int yy = y + tp / 3 - 1, xx = x + tp % 3 - 1;
+                    if ((unsigned)yy < (unsigned)g.n && (unsigned)xx < (unsigned)g.n) m |= 1 << tp;
+                }
+            } else {
+                m = 1;
+            }
+        }
+        vmask[mi] = m;
+        roff[mi] = row * in_stride + kq * 16;
+    }
+    const int zbase = (int)(zrow - act);
+    const uint4* gfr = wg + (size_t)(wn * NI) * 64 + lane;      // k-step s, tile ni: gfr[(s * (NCOLS/16) + ni) * 64]
+    auto wfrag = [&](int s, int ni) { return __builtin_bit_cast(bf16x8, gfr[((size_t)min(s, nks - 1) * (NCOLS / 16) + ni) * 64]); };
+    auto tap_offsets = [&](int (&out)[MI], int tap) {
+        const int dy = three ? tap / 3 - 1 : 0, dx = three ? tap - (tap / 3) * 3 - 1 : 0;
+        const int shift = (dy * g.n + dx) * in_stride;
+        const int bit = tap < ntaps ? 1 << tap : 0;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int reg = roff[mi] + shift;
+            out[mi] = (vmask[mi] & bit) ? reg : zbase + (reg & 255);
+        }
+    };
+    int apc[MI], apn[MI];
+    tap_offsets(apc, 0);
+    bf16x8 a[2][MI], b[DEPTH + 1][NI];
+    static_assert(KPT % 2 == 0 && (KPT % (DEPTH + 1) == 0 || DEPTH == 1), "the fragment rings must keep static indices across taps");
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) b[d][ni] = wfrag(d, ni);
+    __syncthreads();   // the activation image is complete
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) a[0][mi] = *(const bf16x8*)(act + apc[mi]);
+    int s = 0;
+    for (int tap = 0; tap < ntaps; ++tap) {
+        tap_offsets(apn, tap + 1);
+#pragma unroll
+        for (int u = 0; u < KPT; ++u, ++s) {
+            constexpr int NB = DEPTH + 1;
+            const int cur = u % 2, nxt = 1 - cur, bc = u % NB, bn = (u + DEPTH) % NB;
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) b[bn][ni] = wfrag(s + DEPTH, ni);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+                a[nxt][mi] = u + 1 < KPT ? *(const bf16x8*)(act + apc[mi] + (u + 1) * 64) : *(const bf16x8*)(act + apn[mi]);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[bc][ni], a[cur][mi], acc[mi][ni], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);   // keep the loads of later k-steps from being hoisted here (registers)
+        }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) apc[mi] = apn[mi];
+    }
+}
+
 template <int MI, int NI>
 __device__ __forceinline__ void zero_acc(f32x4 (&acc)[MI][NI]) {
 #pragma unroll
@@ -393,8 +471,10 @@ static inline uint16_t f2bf(float f) {
 // row r of tile 2p+e is channel 32*p + 8*(r >> 2) + 4*e + (r & 3).
 // channel_major: the k-steps run over 64-channel chunks first and over the taps inside a chunk (k-step
 // (chunk*taps + tap)*2 + half) instead of tap after tap; cin_pad must then be a multiple of 64.
+// slab_tiles (odd): the tiles are dealt to waves in runs of slab_tiles, and the last tile of a run is not paired:
+// its rows are output channels in natural order.
 static inline std::vector<uint16_t> pack_conv(const std::vector<float>& w, int cout, int cin, int taps, int cin_pad, int ncols,
-                                              bool channel_major = false) {
+                                              bool channel_major = false, int slab_tiles = 0) {
     const int kpt = cin_pad / 32, nks = (taps * kpt + 1) & ~1, ntile = ncols / 16;
     std::vector<uint16_t> out((size_t)nks * ntile * 64 * 8, 0);
     for (int s = 0; s < nks; ++s) {
@@ -407,7 +487,12 @@ static inline std::vector<uint16_t> pack_conv(const std::vector<float>& w, int c
         if (tap >= taps) continue;
         for (int nt = 0; nt < ntile; ++nt)
             for (int l = 0; l < 64; ++l) {
-                const int r = l & 15, co = 32 * (nt >> 1) + 8 * (r >> 2) + 4 * (nt & 1) + (r & 3);
+                const int r = l & 15;
+                int co = 32 * (nt >> 1) + 8 * (r >> 2) + 4 * (nt & 1) + (r & 3);
+                if (slab_tiles & 1) {
+                    const int slab = nt / slab_tiles, e = nt - slab * slab_tiles, base = slab * slab_tiles * 16;
+                    co = e == slab_tiles - 1 ? base + 16 * e + r : base + 32 * (e >> 1) + 8 * (r >> 2) + 4 * (e & 1) + (r & 3);
+                }
                 if (co >= cout) continue;
                 for (int j = 0; j < 8; ++j) {
                     const int ci = c0 + 8 * (l >> 4) + j;

@@ -98,6 +98,25 @@ __device__ __forceinline__ void store_act(const f32x4 (&acc)[MI][NI], const floa
             if (KEEP) xr[(size_t)(mi * (NI / 2) + p) * NT] = pk;
         }
     }
+    if constexpr (NI & 1) {   // the unpaired last tile: 4 consecutive channels per lane (natural row order), 8-byte stores
+        constexpr int e = NI - 1, P2 = NI / 2;
+        const int ch4 = col0 + 32 * P2 + 4 * kq;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (bias) { const float4 x0 = *(const float4*)(bias + ch4); bv[0] = x0.x; bv[1] = x0.y; bv[2] = x0.z; bv[3] = x0.w; }
+        uint2 hold = make_uint2(0, 0);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { v[r] = acc[mi][e][r] + bv[r]; if (RELU) v[r] = fmaxf(v[r], 0.f); }
+            const uint2 pk = make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
+            *(uint2*)(act + (row_base + mi * 16 + lr) * STRIDE + ch4 * 2) = pk;
+            if (KEEP) {   // two tile rows share one 16-byte slot of the residual scratch
+                if (mi & 1) xr[(size_t)(MI * P2 + mi / 2) * NT] = make_uint4(hold.x, hold.y, pk.x, pk.y);
+                else hold = pk;
+            }
+        }
+    }
     __syncthreads();
 }
 
@@ -206,12 +225,16 @@ __device__ __forceinline__ void se_gate(f32x4 (&acc)[MI][NI], const char* act, f
             acc[mi][2 * p][0] *= s0.x; acc[mi][2 * p][1] *= s0.y; acc[mi][2 * p][2] *= s0.z; acc[mi][2 * p][3] *= s0.w;
             acc[mi][2 * p + 1][0] *= s1.x; acc[mi][2 * p + 1][1] *= s1.y; acc[mi][2 * p + 1][2] *= s1.z; acc[mi][2 * p + 1][3] *= s1.w;
         }
+        if constexpr (NI & 1) {
+            const float4 s0 = *(const float4*)(sc + b * C + col0 + 32 * (NI / 2) + 4 * kq);
+            acc[mi][NI - 1][0] *= s0.x; acc[mi][NI - 1][1] *= s0.y; acc[mi][NI - 1][2] *= s0.z; acc[mi][NI - 1][3] *= s0.w;
+        }
     }
 }
 
 // x = relu(y + x) (model.py:40): act <- bf16(x); the new residual goes back to xres when `keep`.
 template <int MI, int NI, int WM, int WN, int STRIDE>
-__device__ __forceinline__ void residual_store(const f32x4 (&acc)[MI][NI], const uint4 (&resv)[MI * NI / 2], char* act, uint4* xres_wg, bool keep) {
+__device__ __forceinline__ void residual_store(const f32x4 (&acc)[MI][NI], const uint4 (&resv)[(MI * NI + 1) / 2], char* act, uint4* xres_wg, bool keep) {
     constexpr int NT = 64 * WM * WN;
     AZ_LANE_GEO(MI, NI, WN);
     __syncthreads();
@@ -235,20 +258,39 @@ __device__ __forceinline__ void residual_store(const f32x4 (&acc)[MI][NI], const
             if (keep) xr[(size_t)(mi * (NI / 2) + p) * NT] = v;
         }
     }
+    if constexpr (NI & 1) {
+        constexpr int e = NI - 1, P2 = NI / 2;
+        const int ch4 = col0 + 32 * P2 + 4 * kq;
+        uint2 hold = make_uint2(0, 0);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const uint4 o = resv[MI * P2 + mi / 2];
+            const uint32_t o0 = (mi & 1) ? o.z : o.x, o1 = (mi & 1) ? o.w : o.y;
+            const uint2 pk = make_uint2(pack_bf16(fmaxf(acc[mi][e][0] + bf16_lo(o0), 0.f), fmaxf(acc[mi][e][1] + bf16_hi(o0), 0.f)),
+                                        pack_bf16(fmaxf(acc[mi][e][2] + bf16_lo(o1), 0.f), fmaxf(acc[mi][e][3] + bf16_hi(o1), 0.f)));
+            *(uint2*)(act + (row_base + mi * 16 + lr) * STRIDE + ch4 * 2) = pk;
+            if (keep) {
+                if (mi & 1) xr[(size_t)(MI * P2 + mi / 2) * NT] = make_uint4(hold.x, hold.y, pk.x, pk.y);
+                else hold = pk;
+            }
+        }
+    }
     __syncthreads();
 }
 
 // C channels; NW = WM x WN waves of 64 positions-by-C/WN channels; NH = padded channel count of the fused
 // head 1x1 convolution, which all NW waves split by positions only. One workgroup per compute unit
 // (LDS-bound), striding over the board groups.
-template <int C, int WM, int WN, int NH>
+// GW > 0: the residual blocks' convolutions read their weight fragments straight from global memory, GW k-steps
+// ahead (gemm_conv_gw: no LDS staging, no barrier inside the loop).
+template <int C, int WM, int WN, int NH, int GW = 0>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_tower(TowerParams P) {
     constexpr int NW = WM * WN, NT = 64 * NW;
     constexpr int MI = 256 / (WM * 16), NI = C / (WN * 16);
     constexpr int MIH = 256 / (NW * 16), NIH = NH / 16;
     constexpr int STRIDE = 2 * C + 32;
-    constexpr int NV = MI * NI / 2;  // 16-byte vectors of packed bf16 residual per thread
-    static_assert(NI % 2 == 0 && NIH % 2 == 0, "channel tiles are stored in pairs");
+    constexpr int NV = (MI * NI + 1) / 2;  // 16-byte vectors of packed bf16 residual per thread
+    static_assert(NIH % 2 == 0 && (NI % 2 == 0 || MI % 2 == 0), "channel tiles are stored in pairs (an unpaired last tile needs an even MI)");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* act = smem;
     constexpr int ZBYTES = ((256 + 2 * C + 16 + 127) / 128) * 128;   // zero region, see gemm_conv
@@ -303,13 +345,15 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_tower(TowerPara
         const size_t conv_vecs = (size_t)NKS * 32 * C * 2 / 16;
         for (int blk = 0; blk < P.blocks; ++blk) {
             zero_acc<MI, NI>(acc);
-            if constexpr (SAME) gemm_conv<MI, NI, WM, WN, C, KPT>(acc, P.w_tower + (size_t)(2 * blk) * conv_vecs, 9, true, act, STRIDE, zrow, bbuf, g);
+            if constexpr (SAME && GW > 0) gemm_conv_gw<MI, NI, WM, WN, C, KPT, GW>(acc, P.w_tower + (size_t)(2 * blk) * conv_vecs, 9, true, act, STRIDE, zrow, g);
+            else if constexpr (SAME) gemm_conv<MI, NI, WM, WN, C, KPT>(acc, P.w_tower + (size_t)(2 * blk) * conv_vecs, 9, true, act, STRIDE, zrow, bbuf, g);
             else gemm_taps<MI, NI, WM, WN, C, false>(acc, P.w_tower + (size_t)(2 * blk) * conv_vecs, NKS, KPT, 9, true, act, STRIDE, zrow, bbuf, g);
             STAMP(2);
             store_act<MI, NI, WM, WN, STRIDE, true, false>(acc, P.b_tower + (size_t)(2 * blk) * C, act, xres_wg);
             STAMP(3);
             zero_acc<MI, NI>(acc);
-            if constexpr (SAME) gemm_conv<MI, NI, WM, WN, C, KPT>(acc, P.w_tower + (size_t)(2 * blk + 1) * conv_vecs, 9, true, act, STRIDE, zrow, bbuf, g);
+            if constexpr (SAME && GW > 0) gemm_conv_gw<MI, NI, WM, WN, C, KPT, GW>(acc, P.w_tower + (size_t)(2 * blk + 1) * conv_vecs, 9, true, act, STRIDE, zrow, g);
+            else if constexpr (SAME) gemm_conv<MI, NI, WM, WN, C, KPT>(acc, P.w_tower + (size_t)(2 * blk + 1) * conv_vecs, 9, true, act, STRIDE, zrow, bbuf, g);
             else gemm_taps<MI, NI, WM, WN, C, false>(acc, P.w_tower + (size_t)(2 * blk + 1) * conv_vecs, NKS, KPT, 9, true, act, STRIDE, zrow, bbuf, g);
             STAMP(2);
             uint4 resv[NV];   // the block input, fetched now, consumed after the SE gate
@@ -329,6 +373,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_tower(TowerPara
                         acc[mi][2 * p][0] += x0.x; acc[mi][2 * p][1] += x0.y; acc[mi][2 * p][2] += x0.z; acc[mi][2 * p][3] += x0.w;
                         acc[mi][2 * p + 1][0] += x1.x; acc[mi][2 * p + 1][1] += x1.y; acc[mi][2 * p + 1][2] += x1.z; acc[mi][2 * p + 1][3] += x1.w;
                     }
+                }
+                if constexpr (NI & 1) {
+                    const float4 x0 = *(const float4*)(P.b_tower + (size_t)(2 * blk + 1) * C + col0 + 32 * (NI / 2) + 4 * kq);
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) { acc[mi][NI - 1][0] += x0.x; acc[mi][NI - 1][1] += x0.y; acc[mi][NI - 1][2] += x0.z; acc[mi][NI - 1][3] += x0.w; }
                 }
             }
             if (P.use_se) {
@@ -576,6 +625,7 @@ struct MfmaNet {
     int hq_rows = 0;
     uint4* xres = nullptr;   // residual-stream scratch for max_grid workgroups
     int max_grid = 0;
+    int split = 0;                // 0: 4x2 waves, weights through LDS; 1: 2x4 waves, weight fragments from global memory (C = 192)
     LayerNet* layers = nullptr;   // set instead of the fused tower's weights when the shape needs the layer-by-layer path
     // optional timing of the tower kernel with HIP events on the launch stream
     bool profiling = false;
@@ -628,6 +678,9 @@ int mfma_create(const az_net_config& c, const NetLayout& L, const float* Pm, Mfm
     m->q = q;
     m->NH = std::max(32, 2 * q);   // policy q + value q channels, in whole tile pairs
     const bool fused = fused_supported(c);
+    m->split = C == 192 ? 1 : 0;
+    if (const char* sp = getenv("AZ_TOWER_SPLIT")) m->split = (C == 192 && atoi(sp) == 1) ? 1 : 0;   // 0 selects the LDS-staged variant
+    const int slab_tiles = m->split == 1 ? 3 : 0;   // channel tiles per wave when that count is odd
     if (fused && tower_lds_bytes(C, m->NH, m->TB, c.se_hidden) > 160 * 1024) { delete m; return fail(AZ_ERR_ARG, "bf16 MFMA path: LDS budget exceeded"); }
     std::vector<float> w, b;
     TowerParams& P = m->P;
@@ -649,7 +702,7 @@ int mfma_create(const az_net_config& c, const NetLayout& L, const float* Pm, Mfm
 #define TRY(x) if ((rc = (x)) != AZ_OK) { mfma_destroy(m); return rc; }
     if (fused) {   // stem
         fold_bn(Pm, L.stem_w, L.stem_bn, C, (int64_t)c.in_planes * 9, w, b);
-        std::vector<uint16_t> pk = pack_conv(w, C, c.in_planes, 9, m->cin_pad, C);
+        std::vector<uint16_t> pk = pack_conv(w, C, c.in_planes, 9, m->cin_pad, C, false, slab_tiles);
         uint16_t* d; float* bd;
         TRY(up(m, pk, &d)); TRY(up(m, b, &bd));
         P.w_stem = (const uint4*)d; P.b_stem = bd;
@@ -662,10 +715,10 @@ int mfma_create(const az_net_config& c, const NetLayout& L, const float* Pm, Mfm
         for (int i = 0; i < c.blocks; ++i) {
             const BlockOff& bo = L.blocks[i];
             fold_bn(Pm, bo.conv1, bo.bn1, C, (int64_t)C * 9, w, b);
-            std::vector<uint16_t> pk = pack_conv(w, C, C, 9, C, C);
+            std::vector<uint16_t> pk = pack_conv(w, C, C, 9, C, C, false, slab_tiles);
             all.insert(all.end(), pk.begin(), pk.end()); ball.insert(ball.end(), b.begin(), b.end());
             fold_bn(Pm, bo.conv2, bo.bn2, C, (int64_t)C * 9, w, b);
-            pk = pack_conv(w, C, C, 9, C, C);
+            pk = pack_conv(w, C, C, 9, C, C, false, slab_tiles);
             all.insert(all.end(), pk.begin(), pk.end()); ball.insert(ball.end(), b.begin(), b.end());
             if (c.use_se) {
                 const int hid = c.se_hidden;
@@ -751,7 +804,10 @@ int mfma_create(const az_net_config& c, const NetLayout& L, const float* Pm, Mfm
         case 32: e = hipFuncSetAttribute((const void*)k_tower<32, 8, 1, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); break;
         case 64: e = hipFuncSetAttribute((const void*)k_tower<64, 4, 2, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); break;
         case 128: e = hipFuncSetAttribute((const void*)k_tower<128, 4, 2, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); break;
-        case 192: e = hipFuncSetAttribute((const void*)k_tower<192, 4, 2, 96>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); break;
+        case 192:
+            e = hipFuncSetAttribute((const void*)k_tower<192, 4, 2, 96>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_tower<192, 2, 4, 96, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            break;
     }
     if (e != hipSuccess) { mfma_destroy(m); return fail(AZ_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); }
     if (!m->w4p) {   // scalar value tail (hidden size above 256): its input image must fit LDS
@@ -950,7 +1006,10 @@ int mfma_forward(MfmaNet* m, const void* feat, int rows, const int* rows_dev, fl
         case 32: hipLaunchKernelGGL((k_tower<32, 8, 1, 32>), dim3(grid), dim3(512), lds, st, P); break;
         case 64: hipLaunchKernelGGL((k_tower<64, 4, 2, 32>), dim3(grid), dim3(512), lds, st, P); break;
         case 128: hipLaunchKernelGGL((k_tower<128, 4, 2, 64>), dim3(grid), dim3(512), lds, st, P); break;
-        case 192: hipLaunchKernelGGL((k_tower<192, 4, 2, 96>), dim3(grid), dim3(512), lds, st, P); break;
+        case 192:
+            if (m->split == 1) hipLaunchKernelGGL((k_tower<192, 2, 4, 96, 2>), dim3(grid), dim3(512), lds, st, P);
+            else hipLaunchKernelGGL((k_tower<192, 4, 2, 96>), dim3(grid), dim3(512), lds, st, P);
+            break;
         default: return fail(AZ_ERR_ARG, "unsupported channel count");
     }
     if (ev) (void)hipEventRecord(ev->second, st);

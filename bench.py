@@ -194,7 +194,7 @@ def main():
         "games_per_hour_note": "moves/s x 3600 / 162 plies (the 9x9 move cap; random-init self-play runs to the cap or two passes)",
         "games_finished_in_window": int(games),
         "mean_leaf_depth": round(depth_sum / max(1.0, sims), 3),
-        "roofline": {"bound": "mfma", "kernel": "k_tower<192,4,2,96>", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS,
+        "roofline": {"bound": "mfma", "kernel": "k_tower<192,2,4,96,2>", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS,
                      "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
                      "traffic": tower_traffic_per_launch(tower_rows / max(1, launches)),
                      "traffic_note": "bytes per launch on the L2's memory side (Infinity Cache hits included), PMC passes in profiles/r01c_tower_hbm_traffic.json; "
