@@ -678,9 +678,10 @@ int mfma_create(const az_net_config& c, const NetLayout& L, const float* Pm, Mfm
     m->q = q;
     m->NH = std::max(32, 2 * q);   // policy q + value q channels, in whole tile pairs
     const bool fused = fused_supported(c);
-    m->split = C == 192 ? 1 : 0;
-    if (const char* sp = getenv("AZ_TOWER_SPLIT")) m->split = (C == 192 && atoi(sp) == 1) ? 1 : 0;   // 0 selects the LDS-staged variant
-    const int slab_tiles = m->split == 1 ? 3 : 0;   // channel tiles per wave when that count is odd
+    m->split = C >= 128 ? 1 : 0;   // measured: 192 ch +3 %, 128 ch +5 %, 64 ch -3 %
+    if (const char* sp = getenv("AZ_TOWER_SPLIT")) m->split = (C >= 64 && atoi(sp) == 1) ? 1 : 0;   // 0 selects the LDS-staged variant
+    const int tiles_per_wave = C / 64;              // 2x4 waves: C/4 channels each
+    const int slab_tiles = (m->split == 1 && (tiles_per_wave & 1)) ? tiles_per_wave : 0;   // channel tiles per wave when that count is odd
     if (fused && tower_lds_bytes(C, m->NH, m->TB, c.se_hidden) > 160 * 1024) { delete m; return fail(AZ_ERR_ARG, "bf16 MFMA path: LDS budget exceeded"); }
     std::vector<float> w, b;
     TowerParams& P = m->P;
@@ -802,8 +803,14 @@ int mfma_create(const az_net_config& c, const NetLayout& L, const float* Pm, Mfm
     hipError_t e = hipSuccess;
     switch (fused ? C : 0) {
         case 32: e = hipFuncSetAttribute((const void*)k_tower<32, 8, 1, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); break;
-        case 64: e = hipFuncSetAttribute((const void*)k_tower<64, 4, 2, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); break;
-        case 128: e = hipFuncSetAttribute((const void*)k_tower<128, 4, 2, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); break;
+        case 64:
+            e = hipFuncSetAttribute((const void*)k_tower<64, 4, 2, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_tower<64, 2, 4, 32, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            break;
+        case 128:
+            e = hipFuncSetAttribute((const void*)k_tower<128, 4, 2, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_tower<128, 2, 4, 64, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            break;
         case 192:
             e = hipFuncSetAttribute((const void*)k_tower<192, 4, 2, 96>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_tower<192, 2, 4, 96, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1004,8 +1011,14 @@ int mfma_forward(MfmaNet* m, const void* feat, int rows, const int* rows_dev, fl
     }
     switch (C) {
         case 32: hipLaunchKernelGGL((k_tower<32, 8, 1, 32>), dim3(grid), dim3(512), lds, st, P); break;
-        case 64: hipLaunchKernelGGL((k_tower<64, 4, 2, 32>), dim3(grid), dim3(512), lds, st, P); break;
-        case 128: hipLaunchKernelGGL((k_tower<128, 4, 2, 64>), dim3(grid), dim3(512), lds, st, P); break;
+        case 64:
+            if (m->split == 1) hipLaunchKernelGGL((k_tower<64, 2, 4, 32, 1>), dim3(grid), dim3(512), lds, st, P);
+            else hipLaunchKernelGGL((k_tower<64, 4, 2, 32>), dim3(grid), dim3(512), lds, st, P);
+            break;
+        case 128:
+            if (m->split == 1) hipLaunchKernelGGL((k_tower<128, 2, 4, 64, 1>), dim3(grid), dim3(512), lds, st, P);
+            else hipLaunchKernelGGL((k_tower<128, 4, 2, 64>), dim3(grid), dim3(512), lds, st, P);
+            break;
         case 192:
             if (m->split == 1) hipLaunchKernelGGL((k_tower<192, 2, 4, 96, 2>), dim3(grid), dim3(512), lds, st, P);
             else hipLaunchKernelGGL((k_tower<192, 4, 2, 96>), dim3(grid), dim3(512), lds, st, P);
