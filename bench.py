@@ -41,7 +41,7 @@ def tower_flops_per_position(n=9, cin=21, ch=CH, blocks=BLOCKS):
 def tower_traffic_per_launch(rows_per_launch):
     """HBM-side bytes per tower launch from the committed PMC summary (separate FETCH_SIZE / WRITE_SIZE passes of
     this benchmark, collected offline: counters cannot be read from inside the run), scaled by rows."""
-    path = os.path.join(ROOT, "profiles", "r01c_tower_hbm_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r01h_tower_hbm_traffic.json")
     try:
         with open(path) as f:
             d = json.load(f)
@@ -197,7 +197,7 @@ def main():
         "roofline": {"bound": "mfma", "kernel": "k_tower<192,2,4,96,2>", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS,
                      "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
                      "traffic": tower_traffic_per_launch(tower_rows / max(1, launches)),
-                     "traffic_note": "bytes per launch on the L2's memory side (Infinity Cache hits included), PMC passes in profiles/r01c_tower_hbm_traffic.json; "
+                     "traffic_note": "bytes per launch on the L2's memory side (Infinity Cache hits included), PMC passes in profiles/r01h_tower_hbm_traffic.json; "
                                      "mostly the bf16 residual stream parked per workgroup between the two convolutions of a block",
                      "launches": int(launches), "avg_launch_ms": round(per_launch_ms, 4),
                      "avg_launch_ms_start_to_end": round(tower_ms_sum / max(1, launches), 4),
