@@ -119,3 +119,50 @@ def test_game_sharding_is_seeded_per_game(tmp_path):
             want = rs.dirichlet([0.3] * 26)
             assert np.array_equal(got[rank][s * 26:(s + 1) * 26], want)
             assert got[rank][6 * 26 + s] == rs.random_sample()
+
+
+def _loop_worker(rank, world, port, save):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from alphazero_amd import train as T
+
+    def fake_selfplay(best_model, cfg, iter_idx, pool=None, model_path=None, model_version=0):
+        # stands in for the GPU self-play of this rank's share: one sample per game, labelled by the game id
+        first, mine = T.rank_share(cfg.selfplay_games_per_iter, rank, world)
+        rs = np.random.RandomState(cfg.seed + iter_idx * 1000 + first)
+        out = []
+        for g in range(mine):
+            planes = np.zeros((2 * cfg.history_len + 5, cfg.board_size, cfg.board_size), np.float32)
+            planes[:-2] = rs.random_sample(planes[:-2].shape) < 0.3
+            pi = rs.dirichlet([0.5] * (cfg.board_size ** 2 + 1)).astype(np.float32)
+            out.append((planes, pi, float(rs.choice([-1.0, 1.0])), 1.0))
+        return out, mine, 0, 0
+
+    def fake_arena(model_a, model_b, cfg, colours):
+        assert rank == 0, "only rank 0 plays arena games"
+        return np.array([1, 1][: len(colours)])          # the candidate wins both distinct games
+
+    T.run_selfplay = fake_selfplay
+    T._arena_results = fake_arena
+    cfg = T.parse_args(["--device", "cpu", "--board-size", "5", "--channels", "32", "--num-blocks", "1", "--value-hidden-dim", "32",
+                        "--iterations", "3", "--selfplay-games-per-iter", "9", "--batch-size", "8", "--train-steps-per-iter", "2",
+                        "--arena-games", "4", "--elo-games-per-opponent", "2", "--benchmark-games-per-opponent", "2",
+                        "--save-dir", save, "--seed", "5"])
+    T.run_training(cfg)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_training_loop_collectives_line_up(tmp_path):
+    """run_training on two ranks with self-play and arena games stubbed out: rank 0 alone plays matches and
+    writes files, both ranks skip iteration 1 (4 and 5 samples < batch 8) and train from iteration 2 on, the
+    promotion decision reaches rank 1, and no rank is left waiting in a collective the other never enters."""
+    save = str(tmp_path / "ck")
+    mp.spawn(_loop_worker, args=(2, _free_port(), save), nprocs=2, join=True)
+    names = set(os.listdir(save))
+    assert {"iter_002.pt", "iter_003.pt", "best.pt", "model_pool.json"} <= names and "iter_001.pt" not in names
+    ck = torch.load(os.path.join(save, "iter_003.pt"), map_location="cpu", weights_only=True)
+    assert ck["iter"] == 3 and ck["promoted"] is True and ck["arena"] == {"wins": 4, "losses": 0, "draws": 0}

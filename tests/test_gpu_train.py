@@ -119,3 +119,70 @@ def test_training_loop_writes_upstream_files(tmp_path, capsys):
     T.run_training(cfg2)           # nothing left to do: start_iter = 3 > iterations
     m, c = T.load_model_from_file(os.path.join(save, "model_pool", "model_iter_000.pt"), "cpu")
     assert c["board_size"] == 5 and m.board_size == 5
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+_TWO_RANK = r"""
+import os, sys, json
+sys.path.insert(0, os.environ["AZ_ROOT"])
+import torch, torch.distributed as dist
+from alphazero_amd import train as T
+rank = int(os.environ["RANK"])
+torch.cuda.set_device(0)
+dist.init_process_group("gloo", rank=rank, world_size=2)
+print("rank", rank, "joined", file=sys.stderr, flush=True)
+cfg = T.parse_args(["--device", "cuda", "--board-size", "5", "--channels", "32", "--num-blocks", "1", "--value-hidden-dim", "64",
+                    "--iterations", "2", "--selfplay-games-per-iter", "10", "--mcts-simulations", "8", "--eval-simulations", "8",
+                    "--mcts-inference-batch", "4", "--batch-size", "32", "--train-steps-per-iter", "3", "--arena-games", "4",
+                    "--elo-games-per-opponent", "2", "--benchmark-games-per-opponent", "2", "--save-dir", os.environ["AZ_SAVE"], "--seed", "5"])
+first, mine = T.rank_share(cfg.selfplay_games_per_iter, rank, 2)
+T.run_training(cfg)
+print("rank", rank, "trained", file=sys.stderr, flush=True)
+dist.barrier()
+if rank == 0:
+    ck = torch.load(os.path.join(cfg.save_dir, "iter_002.pt"), map_location="cpu", weights_only=True)
+    print("RESULT " + json.dumps({"iter": ck["iter"], "promoted": bool(ck["promoted"]), "share": [first, mine]}))
+dist.destroy_process_group()
+"""
+
+
+def test_two_rank_training_loop(tmp_path):
+    """Two ranks (gloo, both on this GPU): the self-play games of an iteration are split over the ranks, gradients are
+    averaged, rank 0 plays the arena and writes the files, and the promotion decision reaches both ranks."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, AZ_ROOT=root, AZ_SAVE=str(tmp_path / "ck"), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE="2")
+    logs = [(open(str(tmp_path / f"rank{r}.out"), "w+"), open(str(tmp_path / f"rank{r}.err"), "w+")) for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, "-u", "-c", _TWO_RANK], env=dict(env, RANK=str(r)), stdout=logs[r][0], stderr=logs[r][1])
+             for r in range(2)]
+    try:
+        for p in procs:
+            p.wait(timeout=240)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    outs = []
+    for o, e in logs:
+        o.seek(0), e.seek(0)
+        outs.append((o.read(), e.read()))
+        o.close(), e.close()
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e[-3000:]
+    line = [ln for ln in outs[0][0].splitlines() if ln.startswith("RESULT ")][0]
+    res = json.loads(line[7:])
+    assert res["iter"] == 2 and res["share"] == [0, 5]
+    names = set(os.listdir(str(tmp_path / "ck")))
+    assert {"iter_001.pt", "iter_002.pt", "model_pool.json"} <= names
+    assert "[Iter 2] selfplay B/W/D=" in outs[0][0] and "[Iter 2]" not in outs[1][0]
+    tally = outs[0][0].split("[Iter 2] selfplay B/W/D=")[1].split()[0]
+    assert sum(int(x) for x in tally.split("/")) == 10          # both ranks' games are counted
