@@ -33,6 +33,7 @@ from .go import BLACK, WHITE, GoState, decode_action
 from .mcts import MCTS
 from .model import AlphaZeroNet
 from .selfplay import choose_opening, opening_book_lines
+from .train_step import all_reduce_, broadcast_
 
 # ----------------------------------------------------------------------------------------------- config
 # (field, default, command line): "value" = --field-name VALUE, "flag" = --field-name sets True,
@@ -650,7 +651,7 @@ def _broadcast_flag(dist, value: bool, device) -> bool:
     if dist is None:
         return value
     t = torch.tensor([1 if value else 0], device=device)
-    dist.broadcast(t, src=0)
+    broadcast_(dist, t, src=0)
     return bool(int(t.item()))
 
 
@@ -676,7 +677,7 @@ def run_training(cfg):
         print(f"[Resume] from {cfg.resume}, next_iter={start_iter}, buffer={len(buffer)}")
     if dist is not None:   # one set of starting weights
         for t in best_model.state_dict().values():
-            dist.broadcast(t, src=0)
+            broadcast_(dist, t, src=0)
     pool = pool_dir = pool_path = None
     runtime_version = 0
     if rank == 0:
@@ -692,8 +693,8 @@ def run_training(cfg):
         if dist is not None:
             tally = torch.tensor([black_wins, white_wins, draws, len(buffer)], device=dev)
             smallest = tally[3:].clone()
-            dist.all_reduce(tally, op=dist.ReduceOp.SUM)
-            dist.all_reduce(smallest, op=dist.ReduceOp.MIN)
+            all_reduce_(dist, tally)
+            all_reduce_(dist, smallest, op=dist.ReduceOp.MIN)
             black_wins, white_wins, draws = (int(x) for x in tally[:3])
             ready = int(smallest.item()) >= cfg.batch_size
         else:
@@ -759,7 +760,7 @@ def run_training(cfg):
                     apply_pbt_mutation(cfg)
                 if dist is not None:
                     knobs = torch.tensor([cfg.lr, cfg.c_init, cfg.dirichlet_eps, float(cfg.temp_moves)], dtype=torch.float64, device=dev)
-                    dist.broadcast(knobs, src=0)
+                    broadcast_(dist, knobs, src=0)
                     cfg.lr, cfg.c_init, cfg.dirichlet_eps, cfg.temp_moves = (float(knobs[0]), float(knobs[1]), float(knobs[2]), int(knobs[3]))
                 stalled = 0
                 if rank == 0:

@@ -22,6 +22,35 @@ def loss_terms(logits, values, target_policies, target_values, huber_delta=1.0, 
     return policy_loss + value_loss - entropy_coeff * entropy, policy_loss, value_loss
 
 
+def _staged(dist, t, group):
+    """gloo moves device tensors through its own pinned buffers and streams, which is seen to stall on ROCm;
+    with that backend a device tensor goes through a host copy made here. RCCL ("nccl") takes it as it is."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def broadcast_(dist, t, src=0, group=None):
+    """dist.broadcast(t) in place, for any backend / device combination this package runs with."""
+    if _staged(dist, t, group):
+        h = t.detach().cpu()
+        dist.broadcast(h, src=src, group=group)
+        t.copy_(h)
+    else:
+        dist.broadcast(t, src=src, group=group)
+    return t
+
+
+def all_reduce_(dist, t, op=None, group=None):
+    """dist.all_reduce(t) in place (default: sum), host-staged under gloo like broadcast_."""
+    op = dist.ReduceOp.SUM if op is None else op
+    if _staged(dist, t, group):
+        h = t.detach().cpu()
+        dist.all_reduce(h, op=op, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op, group=group)
+    return t
+
+
 class DataParallelTrainer:
     def __init__(self, model, lr=1e-3, weight_decay=1e-4, total_steps=800, grad_clip_norm=1.0, huber_delta=1.0,
                  entropy_coeff=1e-3, target_smoothing=0.0, use_amp=False, process_group=None):
@@ -40,7 +69,7 @@ class DataParallelTrainer:
         self._flat = None
         if self.dist:  # identical starting weights on every rank
             for p in model.state_dict().values():
-                self.dist.broadcast(p.data if p.is_floating_point() else p, src=0, group=process_group)
+                broadcast_(self.dist, p.data if p.is_floating_point() else p, src=0, group=process_group)
 
     def _allreduce_grads(self):
         params = [p for p in self.model.parameters() if p.grad is not None]
@@ -51,7 +80,7 @@ class DataParallelTrainer:
             n = p.numel()
             self._flat[off:off + n].copy_(p.grad.reshape(-1))
             off += n
-        self.dist.all_reduce(self._flat, op=self.dist.ReduceOp.SUM, group=self.group)
+        all_reduce_(self.dist, self._flat, group=self.group)
         self._flat.div_(self.world)
         off = 0
         for p in params:
@@ -69,9 +98,9 @@ class DataParallelTrainer:
             logits, values = self.model(states)
             loss, pl, vl = loss_terms(logits, values, target_policies, target_values, self.delta, self.ent)
         self.scaler.scale(loss).backward()
-        self.scaler.unscale_(self.opt)
-        if self.dist and self.world > 1:
+        if self.dist and self.world > 1:   # before unscale_: every rank then sees the same overflow verdict and the same scale
             self._allreduce_grads()
+        self.scaler.unscale_(self.opt)
         torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.clip)
         self.scaler.step(self.opt)
         self.scaler.update()

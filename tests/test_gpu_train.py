@@ -131,7 +131,8 @@ def _free_port():
 
 
 _TWO_RANK = r"""
-import os, sys, json
+import os, sys, json, faulthandler
+faulthandler.dump_traceback_later(120, exit=True)      # a rank stuck in a collective ends with its stack on stderr
 sys.path.insert(0, os.environ["AZ_ROOT"])
 import torch, torch.distributed as dist
 from alphazero_amd import train as T
@@ -166,7 +167,7 @@ def test_two_rank_training_loop(tmp_path):
              for r in range(2)]
     try:
         for p in procs:
-            p.wait(timeout=240)
+            p.wait(timeout=150)
     finally:
         for p in procs:
             if p.poll() is None:
@@ -177,7 +178,7 @@ def test_two_rank_training_loop(tmp_path):
         outs.append((o.read(), e.read()))
         o.close(), e.close()
     for p, (o, e) in zip(procs, outs):
-        assert p.returncode == 0, e[-3000:]
+        assert p.returncode == 0, "rank 0:\n" + outs[0][1][-3000:] + "\nrank 1:\n" + outs[1][1][-3000:]
     line = [ln for ln in outs[0][0].splitlines() if ln.startswith("RESULT ")][0]
     res = json.loads(line[7:])
     assert res["iter"] == 2 and res["share"] == [0, 5]
