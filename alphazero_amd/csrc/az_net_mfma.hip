@@ -431,8 +431,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_tower(TowerPara
         STAMP(6);
     }  // item loop
 #ifdef AZ_STAMP
-    if (tid == 0 && P.stamps)
-        for (int i = 0; i < 16; ++i) P.stamps[(size_t)blockIdx.x * 16 + i] = stamp_acc[i];
+    if ((tid & 63) == 0 && P.stamps)   // one record per wave
+        for (int i = 0; i < 16; ++i) P.stamps[((size_t)blockIdx.x * NW + (tid >> 6)) * 16 + i] = stamp_acc[i];
 #endif
 }
 
@@ -992,7 +992,7 @@ int mfma_forward(MfmaNet* m, const void* feat, int rows, const int* rows_dev, fl
     static int stamp_grid = 0;
     if (grid > stamp_grid) {
         if (stamp_dev) (void)hipFree(stamp_dev);
-        (void)hipMalloc((void**)&stamp_dev, (size_t)grid * 128);
+        (void)hipMalloc((void**)&stamp_dev, (size_t)grid * 8 * 128);
         stamp_grid = grid;
     }
     P.stamps = stamp_dev;
@@ -1031,11 +1031,17 @@ int mfma_forward(MfmaNet* m, const void* feat, int rows, const int* rows_dev, fl
     if (err != hipSuccess) return fail(AZ_ERR_HIP, std::string("bf16 forward: ") + hipGetErrorString(err));
 #ifdef AZ_STAMP
     {   // diagnostic build: print where a workgroup's cycles go (mean over workgroups)
-        std::vector<unsigned long long> hst((size_t)grid * 16);
+        std::vector<unsigned long long> hst((size_t)grid * 8 * 16);   // 8 waves per workgroup in every instantiation
         (void)hipDeviceSynchronize();
         (void)hipMemcpy(hst.data(), P.stamps, hst.size() * 8, hipMemcpyDeviceToHost);
-        double sum[16] = {0};
-        for (int g = 0; g < grid; ++g) for (int i = 0; i < 16; ++i) sum[i] += (double)hst[(size_t)g * 16 + i];
+        double sum[16] = {0}, conv_w[8] = {0};
+        for (int g = 0; g < grid; ++g) {
+            for (int i = 0; i < 16; ++i) sum[i] += (double)hst[(size_t)g * 8 * 16 + i];          // wave 0's view
+            for (int w = 0; w < 8; ++w) conv_w[w] += (double)hst[((size_t)g * 8 + w) * 16 + 2];
+        }
+        fprintf(stderr, "[AZ_STAMP] conv gemm cycles per wave:");
+        for (int w = 0; w < 8; ++w) fprintf(stderr, " %.0f", conv_w[w] / grid);
+        fprintf(stderr, "\n");
         const char* nm[16] = {"load+stem gemm", "stem epilogue", "conv gemm (2/blk)", "conv1 epilogue", "SE scale", "residual epilogue", "head gemm+store",
                               "resv issue+bias+y image", "SE pooling", "SE wait+sync", "SE fc1", "SE fc2", "-", "-", "-", "-"};
         double tot = 0; for (int i = 0; i < 12; ++i) tot += sum[i];
