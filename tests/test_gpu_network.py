@@ -135,3 +135,38 @@ def test_bf16_layer_path(kw):
     assert torch.equal(lg[perm], lg_p) and torch.equal(v[perm], v_p)
     lg_1, v_1 = nn(f[4:5].contiguous())
     assert torch.equal(lg[4:5], lg_1) and torch.equal(v[4:5], v_1)
+
+
+FUSED = [dict(board_size=9, channels=128, num_blocks=2), dict(board_size=7, channels=128, num_blocks=1, history_len=4, use_se=False),
+         dict(board_size=5, channels=192, num_blocks=1, value_hidden_dim=64), dict(board_size=9, channels=192, num_blocks=2, use_se=False),
+         dict(board_size=9, channels=32, num_blocks=2), dict(board_size=6, channels=64, num_blocks=2, history_len=2)]
+
+
+@pytest.mark.parametrize("split", ["default", "0", "1"])
+@pytest.mark.parametrize("kw", FUSED, ids=lambda k: f"n{k['board_size']}_c{k['channels']}")
+def test_bf16_fused_tower_variants(kw, split, monkeypatch):
+    """Every instantiation of the fused tower: weights staged through LDS (AZ_TOWER_SPLIT=0), weight fragments read from
+    global memory (=1), and the default choice per channel count, on board sizes that put 3 to 10 boards in a workgroup."""
+    from alphazero_amd.model import AlphaZeroNet
+    import stubnets
+    if split == "default":
+        monkeypatch.delenv("AZ_TOWER_SPLIT", raising=False)
+    else:
+        monkeypatch.setenv("AZ_TOWER_SPLIT", split)
+    net = _default_init(kw, seed=3)
+    n, c = kw["board_size"], 2 * kw.get("history_len", 8) + 5
+    x = stubnets.synthetic_planes(41, c, n, seed=6)
+    with torch.inference_mode():
+        lg_t, v_t = net(torch.from_numpy(x))
+    dev = torch.device("cuda:0")
+    nn = net.to(dev).native("bf16", shared=False)      # a handle of its own: the variant is chosen when the handle is made
+    assert nn.fused
+    f = _to_nhwc_bf16(x).to(dev)
+    lg, v = nn(f)
+    e_lg, e_val = float((lg.cpu() - lg_t).abs().max()), float((v.cpu() - v_t).abs().max())
+    e_prob = float((lg.cpu().softmax(1) - lg_t.softmax(1)).abs().max())
+    print(f"fused {kw} split={split}: logit err {e_lg:.3g}, value err {e_val:.3g}, prob err {e_prob:.3g}")
+    assert e_lg <= 1e-2 and e_val <= 1e-2 and e_prob <= 1e-2
+    perm = torch.randperm(41)
+    lg_p, v_p = nn(f[perm].contiguous())
+    assert torch.equal(lg[perm], lg_p) and torch.equal(v[perm], v_p)
