@@ -243,33 +243,77 @@ __global__ __launch_bounds__(256) void k_pad_features(const uint4* __restrict__ 
     out[i] = part < 4 ? in[row * 4 + part] : make_uint4(0, 0, 0, 0);
 }
 
-// Squeeze-excite gate of every board (model.py:9-22): mean over the board's positions in index order, two small
-// fully connected layers in float32, sigmoid. One workgroup per board.
+// Squeeze-excite gate of every board (model.py:9-22): mean over the board's positions, two small fully connected
+// layers in float32, sigmoid. One 256-thread workgroup per board. Pooling: C/8 channel groups x 256/(C/8) position
+// phases; a thread adds every phases-th position of its 8 channels (16-byte loads, eight independent sums), then the
+// phases are added in index order. The order depends on the position within the board only, so a board's gate does not
+// depend on where the board sits in the batch.
 __global__ __launch_bounds__(256) void k_se_gate_layer(const uint16_t* __restrict__ y, int np, int C, int hid, const float* __restrict__ w1,
                                                        const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2,
                                                        float* __restrict__ gate) {
-    extern __shared__ float sh[];   // pooled [C], hidden [hid]
-    float* pooled = sh;
-    float* hidden = sh + C;
-    const int b = blockIdx.x;
-    const uint16_t* yb = y + (size_t)b * np * C;
+    extern __shared__ float sh[];   // partial [phases][C], pooled [C], hidden [hid]
+    const int groups = C / 8, phases = 256 / groups;   // C in {64,128,192,256}: 8..32 groups; 192 -> 24 groups, 10 phases
+    float* partial = sh;
+    float* pooled = partial + phases * C;
+    float* hidden = pooled + C;
+    const int t = threadIdx.x, b = blockIdx.x;
+    const int grp = t % groups, ph = t / groups;
+    if (ph < phases) {
+        const uint4* src = (const uint4*)(y + (size_t)b * np * C) + grp;
+        float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int p = ph;
+        for (; p + 3 * phases < np; p += 4 * phases) {   // four loads in flight, added in position order
+            uint4 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = src[(size_t)(p + k * phases) * groups];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                s[0] += bf16_lo(v[k].x); s[1] += bf16_hi(v[k].x); s[2] += bf16_lo(v[k].y); s[3] += bf16_hi(v[k].y);
+                s[4] += bf16_lo(v[k].z); s[5] += bf16_hi(v[k].z); s[6] += bf16_lo(v[k].w); s[7] += bf16_hi(v[k].w);
+            }
+        }
+        for (; p < np; p += phases) {
+            const uint4 v = src[(size_t)p * groups];
+            s[0] += bf16_lo(v.x); s[1] += bf16_hi(v.x); s[2] += bf16_lo(v.y); s[3] += bf16_hi(v.y);
+            s[4] += bf16_lo(v.z); s[5] += bf16_hi(v.z); s[6] += bf16_lo(v.w); s[7] += bf16_hi(v.w);
+        }
+        float* dst = partial + ph * C + grp * 8;
+        *(float4*)dst = make_float4(s[0], s[1], s[2], s[3]);
+        *(float4*)(dst + 4) = make_float4(s[4], s[5], s[6], s[7]);
+    }
+    __syncthreads();
     const float inv = 1.0f / (float)np;
-    for (int ch = threadIdx.x; ch < C; ch += blockDim.x) {
-        float s = 0.f;
-        for (int p = 0; p < np; ++p) s += __uint_as_float((uint32_t)yb[(size_t)p * C + ch] << 16);
-        pooled[ch] = s * inv;
+    for (int ch = t; ch < C; ch += 256) {
+        float a = 0.f;
+        for (int k = 0; k < phases; ++k) a += partial[k * C + ch];
+        pooled[ch] = a * inv;
     }
     __syncthreads();
-    for (int j = threadIdx.x; j < hid; j += blockDim.x) {
-        float s = b1[j];
-        for (int ch = 0; ch < C; ++ch) s = fmaf(w1[j * C + ch], pooled[ch], s);
-        hidden[j] = fmaxf(s, 0.f);
+    {   // fc1 + relu: 8 lanes per hidden unit, each a contiguous run of C/8 channels, fixed reduction tree
+        const int sub = t & 7, run = C / 8;
+        for (int j = t >> 3; j < hid; j += 32) {
+            const float* wr = w1 + (size_t)j * C + sub * run;
+            const float* pr = pooled + sub * run;
+            float a = 0.f;
+            for (int c = 0; c < run; c += 4) {
+                const float4 w = *(const float4*)(wr + c);
+                a = fmaf(w.x, pr[c], a); a = fmaf(w.y, pr[c + 1], a); a = fmaf(w.z, pr[c + 2], a); a = fmaf(w.w, pr[c + 3], a);
+            }
+            a += __shfl_xor(a, 1);
+            a += __shfl_xor(a, 2);
+            a += __shfl_xor(a, 4);
+            if (sub == 0) hidden[j] = fmaxf(a + b1[j], 0.f);
+        }
     }
     __syncthreads();
-    for (int ch = threadIdx.x; ch < C; ch += blockDim.x) {
-        float s = b2[ch];
-        for (int j = 0; j < hid; ++j) s = fmaf(w2[ch * hid + j], hidden[j], s);
-        gate[(size_t)b * C + ch] = 1.f / (1.f + __expf(-s));
+    for (int ch = t; ch < C; ch += 256) {   // fc2 + sigmoid (hid is a multiple of 4: max(8, C/8))
+        const float* wr = w2 + (size_t)ch * hid;
+        float a = b2[ch];
+        for (int j = 0; j < hid; j += 4) {
+            const float4 w = *(const float4*)(wr + j);
+            a = fmaf(w.x, hidden[j], a); a = fmaf(w.y, hidden[j + 1], a); a = fmaf(w.z, hidden[j + 2], a); a = fmaf(w.w, hidden[j + 3], a);
+        }
+        gate[(size_t)b * C + ch] = 1.f / (1.f + __expf(-a));
     }
 }
 
@@ -508,7 +552,7 @@ int layers_tower(LayerNet* m, const uint16_t* feat, int boards, uint16_t* hq, hi
         if (rc != AZ_OK) return rc;
         const float* gate = nullptr;
         if (c.use_se) {
-            hipLaunchKernelGGL(k_se_gate_layer, dim3(boards), dim3(256), (size_t)(C + c.se_hidden) * 4, st, (const uint16_t*)m->y, np, C, c.se_hidden,
+            hipLaunchKernelGGL(k_se_gate_layer, dim3(boards), dim3(256), ((size_t)(256 / (C / 8)) * C + C + c.se_hidden) * 4, st, (const uint16_t*)m->y, np, C, c.se_hidden,
                                m->se[4 * i], m->se[4 * i + 1], m->se[4 * i + 2], m->se[4 * i + 3], m->gate);
             gate = m->gate;
         }
