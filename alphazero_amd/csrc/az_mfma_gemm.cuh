@@ -400,8 +400,16 @@ __device__ __forceinline__ void gemm_conv_gw(f32x4 (&acc)[MI][NI], const uint4* 
         roff[mi] = row * in_stride + kq * 16;
     }
     const int zbase = (int)(zrow - act);
-    const uint4* gfr = wg + (size_t)(wn * NI) * 64 + lane;      // k-step s, tile ni: gfr[(s * (NCOLS/16) + ni) * 64]
-    auto wfrag = [&](int s, int ni) { return __builtin_bit_cast(bf16x8, gfr[((size_t)min(s, nks - 1) * (NCOLS / 16) + ni) * 64]); };
+    // k-step s, tile ni of this wave: byte (s * (NCOLS/16) + wn * NI + ni) * 1024 + lane * 16 of the packed image, read
+    // through a buffer descriptor: per-lane offset fixed for the whole loop, k-step offset in a scalar register, tile
+    // offset an immediate, so a k-step's loads need no vector address arithmetic
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)wg, 0, nks * (NCOLS / 16) * 1024, 0x00020000);
+    const int wvoff = ((wn * NI) * 64 + lane) * 16;
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    auto wfrag = [&](int s, int ni) {
+        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff + ni * 1024, min(s, nks - 1) * (NCOLS / 16) * 1024, 0);
+        return __builtin_bit_cast(bf16x8, v);
+    };
     auto tap_offsets = [&](int (&out)[MI], int tap) {
         const int dy = three ? tap / 3 - 1 : 0, dx = three ? tap - (tap / 3) * 3 - 1 : 0;
         const int shift = (dy * g.n + dx) * in_stride;
