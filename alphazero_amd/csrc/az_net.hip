@@ -187,7 +187,7 @@ int az_net_create(const az_net_config* c, az_net** out) {
         return fail(AZ_ERR_ARG, "unsupported network configuration");
     if (c->precision != AZ_NET_BF16 && c->precision != AZ_NET_F32) return fail(AZ_ERR_ARG, "bad precision");
     if (c->precision == AZ_NET_BF16 && !mfma_supported(*c))
-        return fail(AZ_ERR_ARG, "bf16 MFMA path: unsupported shape (needs channels % 32 == 0, channels <= 256, board <= 9x9 for this build)");
+        return fail(AZ_ERR_ARG, "bf16 MFMA path: unsupported shape (channels 32/64/128/192 on boards up to 9x9, 64/128/192/256 with at most 32 input planes on boards up to 19x19)");
     az_net* net = new az_net();
     net->cfg = *c;
     net_layout(*c, net->L);
