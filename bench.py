@@ -193,6 +193,7 @@ def main():
         "games_per_hour_est": round(moves / dt_max * 3600 / 162, 1),
         "games_per_hour_note": "moves/s x 3600 / 162 plies (the 9x9 move cap; random-init self-play runs to the cap or two passes)",
         "games_finished_in_window": int(games),
+        "games_per_hour_measured": round(games / dt_max * 3600, 1),   # meaningful for windows of a few hundred steps (--steps 330)
         "mean_leaf_depth": round(depth_sum / max(1.0, sims), 3),
         "roofline": {"bound": "mfma", "kernel": "k_tower<192,2,4,96,2>", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS,
                      "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
