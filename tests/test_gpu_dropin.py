@@ -84,6 +84,32 @@ def test_mcts_run_matches_upstream(c):
     assert len(out) == 2 and out[1] == c["action"]
 
 
+def _root_parallel_cases():
+    z = golden_io.load("root_parallel")
+    out = []
+    for c in json.loads(bytes(z["cases_json"]).decode()):
+        k = c["name"]
+        out.append(dict(c, root_actions=z[f"{k}/root_actions"], pi=z[f"{k}/pi"], action=int(z[f"{k}/action"][0]),
+                        root_value=float(z[f"{k}/root_value"][0])))
+    return out
+
+
+@pytest.mark.parametrize("c", _root_parallel_cases(), ids=lambda c: c["name"])
+def test_mcts_run_with_several_roots_matches_upstream(c):
+    """mcts.py:240-268: simulations split over root_parallelism roots, visits summed, root values weighted by the
+    simulation counts (upstream's threaded result without exploration noise, which is the reproducible case)."""
+    from go_zero import GoState, MCTS, decode_action
+    st = GoState.new_game(board_size=c["n"], komi=5.5, history_len=8)
+    for a in c["root_actions"]:
+        st = st.play(decode_action(c["n"], int(a)))
+    m = MCTS(_Stub(c["kind"]), board_size=c["n"], num_simulations=c["sims"], inference_batch_size=c["B"], topk_expand=c["K"],
+             virtual_loss=c["VL"], root_parallelism=c["roots"], device="cpu")
+    np.random.seed(c["rseed"])
+    pi, action, rv = m.run(st, temperature=c["T"], add_exploration_noise=False, return_root_value=True)
+    assert pi.dtype == np.float32 and pi.tobytes() == c["pi"].tobytes()
+    assert action == c["action"] and rv == c["root_value"]
+
+
 def test_mcts_terminal_root():
     from go_zero import GoState, MCTS
     st = GoState.new_game(5).play(None).play(None)
