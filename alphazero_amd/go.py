@@ -5,6 +5,7 @@ There is no CPU implementation of the rules in this package.
 """
 from __future__ import annotations
 
+import threading
 from dataclasses import dataclass, field
 from typing import Optional
 
@@ -30,6 +31,9 @@ def tensor_channels(history_len: int) -> int:
 
 
 _ENGINES: dict = {}
+# States are values and may be queried from any thread (the scripts search on a worker thread and keep using states on
+# the main one); the one-game engine behind the queries holds one state at a time, so upload + query is one critical section.
+_ENGINE_LOCK = threading.RLock()
 
 
 def _engine(n: int, hist: int, komi: float):
@@ -108,13 +112,14 @@ class GoState:
 
     def _evaluated(self) -> dict:
         c = self._cache
-        if "legal" not in c:
-            eng = self._upload()
-            score, info = eng.status()
-            c["legal"] = eng.legal_mask().cpu().numpy()[0].astype(bool)
-            c["tensor"] = eng.features().cpu().numpy()[0]
-            c["score"] = tuple(float(x) for x in score.cpu().numpy()[0])
-            c["winner"] = int(info.cpu().numpy()[0, 7])
+        if "winner" not in c:
+            with _ENGINE_LOCK:
+                eng = self._upload()
+                score, info = eng.status()
+                c["legal"] = eng.legal_mask().cpu().numpy()[0].astype(bool)
+                c["tensor"] = eng.features().cpu().numpy()[0]
+                c["score"] = tuple(float(x) for x in score.cpu().numpy()[0])
+                c["winner"] = int(info.cpu().numpy()[0, 7])   # written last: the key the check above looks for
         return c
 
     # ---------------------------------------------------------------- upstream methods
@@ -133,9 +138,10 @@ class GoState:
         n, h = self.board_size, self.history_len
         if move is not None and not self.is_legal(move):
             raise ValueError(f"Illegal move: {move}")
-        eng = self._upload()
-        eng.play([encode_action(n, move)])
-        board, hist, sc, seen = (t.cpu().numpy() for t in eng.export_state())
+        with _ENGINE_LOCK:
+            eng = self._upload()
+            eng.play([encode_action(n, move)])
+            board, hist, sc, seen = (t.cpu().numpy() for t in eng.export_state())
         sc = sc[0]
         nh = int(sc[6])
         return GoState(board=board[0].reshape(n, n).copy(), to_play=int(sc[0]), consecutive_passes=int(sc[1]),

@@ -4,6 +4,8 @@ only sequences the calls, feeds the evaluator and applies the temperature exactl
 """
 from __future__ import annotations
 
+import threading
+
 import numpy as np
 import torch
 
@@ -40,6 +42,7 @@ class MCTS:
         self.root_parallelism = max(1, int(root_parallelism))
         self.device = device          # where `model` is evaluated; the search itself always runs on the GPU
         self._engines: dict = {}
+        self._lock = threading.RLock()   # one search at a time per object: its engines hold the tree being searched
 
     # ------------------------------------------------------------------ plumbing
     def _engine(self, state: GoState, sims: int) -> Engine:
@@ -76,11 +79,12 @@ class MCTS:
 
     def _run_single_root_search(self, root_state: GoState, add_exploration_noise: bool, simulations: int):
         """mcts.py:165-225 -> (visits float64 [A], root value)."""
-        eng = self._engine(root_state, simulations)
-        eng.import_state(*root_state._packed(eng.seen_cap))
-        layout, fn = self._evaluator()
-        visits, rv = eng.run_search(fn, add_noise=add_exploration_noise, rngs=np.random, layout=layout)
-        return visits.cpu().numpy()[0].astype(np.float64), float(rv.cpu()[0])
+        with self._lock:
+            eng = self._engine(root_state, simulations)
+            eng.import_state(*root_state._packed(eng.seen_cap))
+            layout, fn = self._evaluator()
+            visits, rv = eng.run_search(fn, add_noise=add_exploration_noise, rngs=np.random, layout=layout)
+            return visits.cpu().numpy()[0].astype(np.float64), float(rv.cpu()[0])
 
     # ------------------------------------------------------------------ upstream entry point
     def run(self, root_state: GoState, temperature: float = 1.0, add_exploration_noise: bool = True,

@@ -287,3 +287,27 @@ def test_root_reuse_plays_the_same_games_with_fewer_evaluations(use_async):
     assert a.counters["moves"] == b.counters["moves"]
     saved = b.counters["nn_rows"] - a.counters["nn_rows"]
     assert saved == a.counters["moves"] - 9          # every move but the first of each of the 9 games
+
+
+def test_mcts_run_from_worker_threads():
+    """The scripts call MCTS.run from a UI worker thread (battle_ui_pyqt.py:178) and GoState methods from the main
+    thread in between: one MCTS object, reused across threads and moves, gives the main-thread result."""
+    import threading
+    from go_zero import GoState, MCTS
+    st = GoState.new_game(board_size=5).play((2, 2)).play((1, 1))
+    m = MCTS(_Stub("hash"), board_size=5, num_simulations=24, inference_batch_size=4, device="cpu")
+    want = m.run(st, temperature=1e-6, add_exploration_noise=False, return_root_value=True)
+    got = [None, None]
+
+    def work(i, state):
+        got[i] = m.run(state, temperature=1e-6, add_exploration_noise=False, return_root_value=True)
+
+    threads = [threading.Thread(target=work, args=(i, st)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    for g in got:
+        assert g is not None and g[0].tobytes() == want[0].tobytes() and g[1] == want[1] and g[2] == want[2]
+    nxt = st.play(divmod(want[1], 5))                       # the caller goes on with the state on its own thread
+    assert nxt.move_count == 3 and nxt.to_play == st.to_play * -1
