@@ -28,6 +28,7 @@ struct ConvArgs {
     const float* bias;     // [cout]
     char* out;             // [rows][out_stride bytes] bf16
     int out_stride, rows, n, np, ntaps, relu;
+    int col_blocks;        // k_conv3_slab: blocks of NCOLS output channels (1-D grid, see slab_block)
 };
 
 template <int KPT, int NCOLS, int WM, int WN>
@@ -86,8 +87,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_conv3_slab(Conv
     char* bbuf = zreg + 1024;                  // two weight tiles
     AZ_LANE_GEO(MI, NI, WN);
     const int n = a.n, np = a.np, halo = n + 1, srows = 256 + 2 * halo;
-    const int row0 = blockIdx.x * 256, C2 = a.in_stride, nkc = a.in_stride / 128, ntiles = nkc * 9;
-    const uint4* wg = a.w + (size_t)blockIdx.y * a.w_block_vecs;
+    // 1-D grid; workgroups are dealt round-robin over the 8 XCDs, so ids 8 apart share an L2: the column blocks of one
+    // row tile get ids 8 apart and fetch the tile's activations into one L2 instead of one L2 each
+    const int per_group = 8 * a.col_blocks, grp = blockIdx.x / per_group, within = blockIdx.x - grp * per_group;
+    const int bx = grp * 8 + (within & 7), by = within >> 3;
+    if (bx * 256 >= a.rows) return;   // padding of the last group of 8 row tiles (whole workgroup, before any barrier)
+    const int row0 = bx * 256, C2 = a.in_stride, nkc = a.in_stride / 128, ntiles = nkc * 9;
+    const uint4* wg = a.w + (size_t)by * a.w_block_vecs;
     for (int i = t_; i < 256; i += NT) ((uint32_t*)zreg)[i] = 0;
     stage_tile<NW>(wg, bbuf, nvec, lane, wave);
     stage_tile<NW>(wg + nvec, bbuf + tile_bytes, nvec, lane, wave);
@@ -213,7 +219,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_conv3_slab(Conv
         }
     }
     // epilogue: bias, ReLU, bf16 rows to global memory
-    const int cbase = blockIdx.y * NCOLS + col0 + 8 * kq;
+    const int cbase = by * NCOLS + col0 + 8 * kq;
 #pragma unroll
     for (int p = 0; p < NI / 2; ++p) {
         const float4 x0 = *(const float4*)(a.bias + cbase + 32 * p), x1 = *(const float4*)(a.bias + cbase + 32 * p + 4);
@@ -492,8 +498,11 @@ static int launch_slab(const ConvArgs& a, int cout, hipStream_t st) {
             return fail(AZ_ERR_HIP, "hipFuncSetAttribute (k_conv3_slab)");
         opted = true;
     }
-    const dim3 grid((a.rows + 255) / 256, (cout + NCOLS - 1) / NCOLS);
-    hipLaunchKernelGGL((k_conv3_slab<NCOLS, 4, 2>), grid, dim3(512), lds, st, a);
+    ConvArgs b = a;
+    b.col_blocks = (cout + NCOLS - 1) / NCOLS;
+    const int row_tiles = (a.rows + 255) / 256;
+    const dim3 grid((unsigned)((row_tiles + 7) / 8 * 8 * b.col_blocks));
+    hipLaunchKernelGGL((k_conv3_slab<NCOLS, 4, 2>), grid, dim3(512), lds, st, b);
     return AZ_OK;
 }
 
@@ -502,7 +511,7 @@ static int launch_conv(const PackedConv& pc, const char* in, int zero_off, char*
                        hipStream_t st) {
     ConvArgs a;
     a.in = in; a.in_stride = pc.cin_pad * 2; a.zero_off = zero_off; a.w = pc.w; a.w_block_vecs = pc.block_vecs; a.bias = pc.b;
-    a.out = out; a.out_stride = out_stride; a.rows = rows; a.n = n; a.np = n * n; a.ntaps = pc.taps; a.relu = relu;
+    a.out = out; a.out_stride = out_stride; a.rows = rows; a.n = n; a.np = n * n; a.ntaps = pc.taps; a.relu = relu; a.col_blocks = 1;
     const int key = (pc.cin_pad / 32) * 1000 + pc.ncols;
     if (pc.slab && n + 1 <= kMaxHalo) {
         switch (pc.ncols) {
