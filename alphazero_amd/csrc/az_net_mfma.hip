@@ -917,8 +917,14 @@ void mfma_destroy(MfmaNet* m) {
 static void run_tails(MfmaNet* m, const uint16_t* hq_in, int rows, const int* rows_dev, float* logits, float* values, hipStream_t st) {
     const az_net_config& c = m->cfg;
     const int np = c.board_size * c.board_size, q = m->q;
-    hipLaunchKernelGGL((k_policy_tail<8>), dim3((rows + 7) / 8), dim3(256), (size_t)8 * 2 * np * 4, st, hq_in, m->w3, m->b3, m->wfcT, m->bfc, logits, rows,
-                       np, q, rows_dev);
+    // boards per workgroup by board size only (a board's sums run in the same order either way): large boards come in
+    // chunks of a few hundred rows, which 8 per workgroup would spread over too few CUs
+    if (np <= 81)
+        hipLaunchKernelGGL((k_policy_tail<8>), dim3((rows + 7) / 8), dim3(256), (size_t)8 * 2 * np * 4, st, hq_in, m->w3, m->b3, m->wfcT, m->bfc, logits, rows,
+                           np, q, rows_dev);
+    else
+        hipLaunchKernelGGL((k_policy_tail<2>), dim3((rows + 1) / 2), dim3(256), (size_t)2 * 2 * np * 4, st, hq_in, m->w3, m->b3, m->wfcT, m->bfc, logits, rows,
+                           np, q, rows_dev);
     if (m->w4p) {
         const dim3 vg((rows + 15) / 16);
         const uint4* wp = (const uint4*)m->w4p;
