@@ -532,7 +532,7 @@ __global__ __launch_bounds__(256) void k_value_tail(const uint16_t* __restrict__
 template <int NTW>
 __global__ __launch_bounds__(256) void k_value_tail_mfma(const uint16_t* __restrict__ hq, const uint4* __restrict__ w4p, const float* __restrict__ b4p,
                                                          const float* __restrict__ w6p, const float* __restrict__ b6, float* __restrict__ values,
-                                                         int rows, int np, int q, int nks, int ntiles, unsigned recip_qc, const int* rows_dev) {
+                                                         int rows, int np, int q, int nks, int ntiles, unsigned recip_qc, const int* rows_dev, float* part_out, int part_stride) {
     __shared__ float red[4][16];
     if (rows_dev) rows = min(rows, *rows_dev);
     const int r0 = blockIdx.x * 16;
@@ -541,7 +541,8 @@ __global__ __launch_bounds__(256) void k_value_tail_mfma(const uint16_t* __restr
     const int row = min(r0 + li, rows - 1);
     const int qc = q >> 3, nfrag = np * qc;
     const uint16_t* abase = hq + (size_t)row * np * 2 * q + q;   // the value half of this board's head activations
-    const uint4* bbase = w4p + (size_t)wave * 64 + lane;         // tile `wave` of k-step 0; tiles wave + 4t follow at +256t vectors
+    const int t0 = blockIdx.y * NTW;                             // split launch: this workgroup's share of the unit tiles
+    const uint4* bbase = w4p + (size_t)wave * 64 + lane + (size_t)t0 * 256;   // tile `wave + 4 t0` of k-step 0; tiles wave + 4(t0 + t) follow at +256t vectors
     const size_t kstride = (size_t)ntiles * 64;
     const uint4 zero4 = make_uint4(0, 0, 0, 0);
     auto load_a = [&](int s) -> uint4 {
@@ -563,7 +564,7 @@ __global__ __launch_bounds__(256) void k_value_tail_mfma(const uint16_t* __restr
             a[d] = load_a(d);
 #pragma unroll
             for (int t = 0; t < NTW; ++t)
-                if (wave + 4 * t < ntiles) b[d][t] = bbase[(size_t)d * kstride + t * 256];
+                if (wave + 4 * (t0 + t) < ntiles) b[d][t] = bbase[(size_t)d * kstride + t * 256];
         }
     }
     for (int s = 0; s < nks; s += 4) {
@@ -577,7 +578,7 @@ __global__ __launch_bounds__(256) void k_value_tail_mfma(const uint16_t* __restr
                     a[d] = load_a(s + d + 4);
 #pragma unroll
                     for (int t = 0; t < NTW; ++t)
-                        if (wave + 4 * t < ntiles) b[d][t] = bbase[(size_t)(s + d + 4) * kstride + t * 256];
+                        if (wave + 4 * (t0 + t) < ntiles) b[d][t] = bbase[(size_t)(s + d + 4) * kstride + t * 256];
                 }
             }
         }
@@ -586,8 +587,9 @@ __global__ __launch_bounds__(256) void k_value_tail_mfma(const uint16_t* __restr
     float part[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < NTW; ++t) {
-        const int j = (wave + 4 * t) * 16 + li;
-        const float bb = wave + 4 * t < ntiles ? b4p[j] : 0.f, ww = wave + 4 * t < ntiles ? w6p[j] : 0.f;
+        const int j = (wave + 4 * (t0 + t)) * 16 + li;
+        const bool live = wave + 4 * (t0 + t) < ntiles;
+        const float bb = live ? b4p[j] : 0.f, ww = live ? w6p[j] : 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) part[r] = fmaf(ww, fmaxf(acc[t][r] + bb, 0.f), part[r]);
     }
@@ -605,8 +607,21 @@ __global__ __launch_bounds__(256) void k_value_tail_mfma(const uint16_t* __restr
     __syncthreads();
     if (threadIdx.x < 16 && r0 + (int)threadIdx.x < rows) {
         const int i = threadIdx.x;
-        values[r0 + i] = tanhf(((red[0][i] + red[1][i]) + (red[2][i] + red[3][i])) + b6[0]);
+        const float sum = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+        if (part_out) part_out[(size_t)(r0 + i) * part_stride + blockIdx.y] = sum;   // split launch: k_value_finish adds the shares
+        else values[r0 + i] = tanhf(sum + b6[0]);
     }
+}
+
+// Second half of a split value tail: value = tanh(sum of the workgroups' shares in index order + b6).
+__global__ __launch_bounds__(256) void k_value_finish(const float* __restrict__ part, int shares, const float* __restrict__ b6, float* __restrict__ values,
+                                                      int rows, const int* rows_dev) {
+    if (rows_dev) rows = min(rows, *rows_dev);
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    float s = 0.f;
+    for (int k = 0; k < shares; ++k) s += part[(size_t)r * shares + k];
+    values[r] = tanhf(s + b6[0]);
 }
 
 // ------------------------------------------------------------------------------------------------ host
@@ -623,6 +638,7 @@ struct MfmaNet {
     unsigned v_recip = 0;
     uint16_t* hq = nullptr;
     int hq_rows = 0;
+    float* vpart = nullptr;       // split value tail: [chunk rows][shares] partial sums, allocated with hq (layer path, large boards)
     uint4* xres = nullptr;   // residual-stream scratch for max_grid workgroups
     int max_grid = 0;
     int split = 0;                // 0: 4x2 waves, weights through LDS; 1: 2x4 waves, weight fragments from global memory (C = 192)
@@ -908,6 +924,7 @@ void mfma_destroy(MfmaNet* m) {
     for (auto& e : m->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     for (void* p : m->allocs) (void)hipFree(p);
     if (m->hq) (void)hipFree(m->hq);
+    if (m->vpart) (void)hipFree(m->vpart);
     if (m->xres) (void)hipFree(m->xres);
     if (m->layers) layers_destroy(m->layers);
     delete m;
@@ -928,11 +945,20 @@ static void run_tails(MfmaNet* m, const uint16_t* hq_in, int rows, const int* ro
     if (m->w4p) {
         const dim3 vg((rows + 15) / 16);
         const uint4* wp = (const uint4*)m->w4p;
-        switch ((m->v_ntiles + 3) / 4) {
-            case 1: hipLaunchKernelGGL((k_value_tail_mfma<1>), vg, dim3(256), 0, st, hq_in, wp, m->b4p, m->w6p, m->b6, values, rows, np, q, m->v_nks, m->v_ntiles, m->v_recip, rows_dev); break;
-            case 2: hipLaunchKernelGGL((k_value_tail_mfma<2>), vg, dim3(256), 0, st, hq_in, wp, m->b4p, m->w6p, m->b6, values, rows, np, q, m->v_nks, m->v_ntiles, m->v_recip, rows_dev); break;
-            case 3: hipLaunchKernelGGL((k_value_tail_mfma<3>), vg, dim3(256), 0, st, hq_in, wp, m->b4p, m->w6p, m->b6, values, rows, np, q, m->v_nks, m->v_ntiles, m->v_recip, rows_dev); break;
-            default: hipLaunchKernelGGL((k_value_tail_mfma<4>), vg, dim3(256), 0, st, hq_in, wp, m->b4p, m->w6p, m->b6, values, rows, np, q, m->v_nks, m->v_ntiles, m->v_recip, rows_dev); break;
+        const int shares = (m->v_ntiles + 3) / 4;
+        if (m->vpart && shares > 1) {
+            // large boards (long K, chunks of a few hundred rows): the unit tiles are dealt to `shares` workgroups per 16
+            // boards, one tile per wave, and a second kernel adds the shares in index order. Chosen by shape only.
+            hipLaunchKernelGGL((k_value_tail_mfma<1>), dim3(vg.x, shares), dim3(256), 0, st, hq_in, wp, m->b4p, m->w6p, m->b6, values, rows, np, q, m->v_nks,
+                               m->v_ntiles, m->v_recip, rows_dev, m->vpart, shares);
+            hipLaunchKernelGGL(k_value_finish, dim3((rows + 255) / 256), dim3(256), 0, st, (const float*)m->vpart, shares, m->b6, values, rows, rows_dev);
+            return;
+        }
+        switch (shares) {
+            case 1: hipLaunchKernelGGL((k_value_tail_mfma<1>), vg, dim3(256), 0, st, hq_in, wp, m->b4p, m->w6p, m->b6, values, rows, np, q, m->v_nks, m->v_ntiles, m->v_recip, rows_dev, (float*)nullptr, 0); break;
+            case 2: hipLaunchKernelGGL((k_value_tail_mfma<2>), vg, dim3(256), 0, st, hq_in, wp, m->b4p, m->w6p, m->b6, values, rows, np, q, m->v_nks, m->v_ntiles, m->v_recip, rows_dev, (float*)nullptr, 0); break;
+            case 3: hipLaunchKernelGGL((k_value_tail_mfma<3>), vg, dim3(256), 0, st, hq_in, wp, m->b4p, m->w6p, m->b6, values, rows, np, q, m->v_nks, m->v_ntiles, m->v_recip, rows_dev, (float*)nullptr, 0); break;
+            default: hipLaunchKernelGGL((k_value_tail_mfma<4>), vg, dim3(256), 0, st, hq_in, wp, m->b4p, m->w6p, m->b6, values, rows, np, q, m->v_nks, m->v_ntiles, m->v_recip, rows_dev, (float*)nullptr, 0); break;
         }
     } else {
         const size_t vt = ((size_t)4 * q * np + 4 * c.value_hidden) * 4;
@@ -953,6 +979,12 @@ int mfma_forward(MfmaNet* m, const void* feat, int rows, const int* rows_dev, fl
             m->hq = nullptr;
             if (hipMalloc((void**)&m->hq, (size_t)chunk * np * 2 * q * 2) != hipSuccess) return fail(AZ_ERR_HIP, "hipMalloc (head scratch)");
             m->hq_rows = chunk;
+            if (np > 81 && m->w4p && m->v_ntiles > 4) {   // split value tail (run_tails)
+                if (m->vpart) (void)hipFree(m->vpart);
+                m->vpart = nullptr;
+                if (hipMalloc((void**)&m->vpart, (size_t)(chunk + 16) * ((m->v_ntiles + 3) / 4) * sizeof(float)) != hipSuccess)
+                    return fail(AZ_ERR_HIP, "hipMalloc (value tail scratch)");
+            }
         }
         std::pair<hipEvent_t, hipEvent_t>* evl = nullptr;
         if (m->profiling) {
