@@ -475,7 +475,17 @@ __global__ __launch_bounds__(256) void k_policy_tail(const uint16_t* __restrict_
 #pragma unroll
         for (int r = 0; r < RH; ++r) acc[r] = bfc[a];
         const float* fl = flat + hsel * RH * F;
-        for (int i = 0; i < F; ++i) {
+        int i = 0;
+        for (; i + 8 <= F; i += 8) {   // eight weight loads in flight; the sums keep their order
+            float w[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) w[k] = wfcT[(size_t)(i + k) * A + a];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+#pragma unroll
+                for (int r = 0; r < RH; ++r) acc[r] = fmaf(w[k], fl[r * F + i + k], acc[r]);
+        }
+        for (; i < F; ++i) {
             const float w = wfcT[(size_t)i * A + a];
 #pragma unroll
             for (int r = 0; r < RH; ++r) acc[r] = fmaf(w, fl[r * F + i], acc[r]);
