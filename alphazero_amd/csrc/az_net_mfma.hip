@@ -1007,8 +1007,9 @@ int mfma_forward(MfmaNet* m, const void* feat, int rows, const int* rows_dev, fl
             m->prof_rows += rows;
             (void)hipEventRecord(evl->first, st);
         }
-        for (int off = 0; off < rows; off += chunk) {
-            const int nb = std::min(chunk, rows - off);
+        const int nchunks = (rows + chunk - 1) / chunk, per = (rows + nchunks - 1) / nchunks;   // even shares: no small last chunk
+        for (int off = 0; off < rows; off += per) {
+            const int nb = std::min(per, rows - off);
             int rc = layers_tower(m->layers, (const uint16_t*)feat + (size_t)off * np * 32, nb, m->hq, st);
             if (rc != AZ_OK) return rc;
             run_tails(m, m->hq, nb, nullptr, logits + (size_t)off * A, values + off, st);
