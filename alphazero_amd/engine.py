@@ -192,8 +192,16 @@ class Engine:
         return dict(zip(keys, [int(x) for x in out]))
 
     # ------------------------------------------------------------------ whole search with a host evaluator
+    def _async_buffers(self):
+        """Buffers of the sync-free batch loop (allocated once): features for max_rows rows, logits, values."""
+        if getattr(self, "_abuf", None) is None:
+            self._abuf = (self._t((self.max_rows, self.n * self.n, self.cpad), torch.bfloat16),
+                          self._t((self.max_rows, self.A), torch.float32), self._t((self.max_rows,), torch.float32),
+                          self.rows_device())
+        return self._abuf
+
     def run_search(self, evaluator, add_noise=False, rngs=None, enable=None, layout=N.AZ_FEAT_F32_NCHW,
-                   capture_priors=None):
+                   capture_priors=None, native_net=None):
         """mcts.py:165-225 for all games. `evaluator(features) -> (logits, values)` gets a device tensor in
         `layout` and returns tensors [rows, A] / [rows]. `rngs`: one numpy RandomState-like object per game
         (or a single one, used game after game) that supplies the root Dirichlet sample exactly where the
@@ -218,6 +226,22 @@ class Engine:
                 capture_priors.append(self.last_priors(rows).cpu().numpy())
         else:
             done = True
+        if (not done and native_net is not None and capture_priors is None and layout == N.AZ_FEAT_BF16_NHWC
+                and getattr(native_net, "fused", False)):
+            # the fused bf16 network reads the row count on the device: all batches are enqueued without a round trip
+            fb, lb, vb, rows_dev = self._async_buffers()
+            self.set_async(True)
+            try:
+                while not done:
+                    self.search_select()
+                    self.gather(self.max_rows, layout, out=fb)
+                    native_net.forward_indirect(fb, rows_dev, self.max_rows, lb, vb)
+                    done = self.expand(lb, vb)
+                out = self.result()
+                self.stats()          # reports a failed select / exhausted node pool of the enqueued batches
+            finally:
+                self.set_async(False)
+            return out
         while not done:
             self.search_select()
             rows = self.pending()

@@ -57,15 +57,16 @@ class MCTS:
         return eng
 
     def _evaluator(self):
-        """(layout, fn): fn maps a device feature tensor to (logits, values) float32 device tensors."""
+        """(layout, fn, net): fn maps a device feature tensor to (logits, values) float32 device tensors; net is the
+        native network handle behind fn, if any (its fused kind lets the engine enqueue a search without round trips)."""
         model, dev = self.model, str(self.device)
         if isinstance(model, AlphaZeroNet) and not model.training and next(model.parameters()).is_cuda:
             try:
                 net = model.native("bf16")
-                return N.AZ_FEAT_BF16_NHWC, net.forward
+                return N.AZ_FEAT_BF16_NHWC, net.forward, net
             except N.NativeError:
                 net = model.native("f32")
-                return N.AZ_FEAT_F32_NCHW, net.forward
+                return N.AZ_FEAT_F32_NCHW, net.forward, None
 
         def generic(feats):   # any callable x[b,C,n,n] -> (logits, value), evaluated where upstream would (mcts.py:59-66)
             with torch.inference_mode():
@@ -75,15 +76,15 @@ class MCTS:
             return (torch.as_tensor(logits).detach().to(feats.device, torch.float32),
                     torch.as_tensor(value).detach().to(feats.device, torch.float32))
 
-        return N.AZ_FEAT_F32_NCHW, generic
+        return N.AZ_FEAT_F32_NCHW, generic, None
 
     def _run_single_root_search(self, root_state: GoState, add_exploration_noise: bool, simulations: int):
         """mcts.py:165-225 -> (visits float64 [A], root value)."""
         with self._lock:
             eng = self._engine(root_state, simulations)
             eng.import_state(*root_state._packed(eng.seen_cap))
-            layout, fn = self._evaluator()
-            visits, rv = eng.run_search(fn, add_noise=add_exploration_noise, rngs=np.random, layout=layout)
+            layout, fn, net = self._evaluator()
+            visits, rv = eng.run_search(fn, add_noise=add_exploration_noise, rngs=np.random, layout=layout, native_net=net)
             return visits.cpu().numpy()[0].astype(np.float64), float(rv.cpu()[0])
 
     # ------------------------------------------------------------------ upstream entry point

@@ -450,9 +450,9 @@ def _arena_results(model_a, model_b, cfg, colours):
         m.eval()
         if next(m.parameters()).is_cuda:
             net = m.native("bf16", eng.device)
-            evs.append((net.forward, net.layout))
+            evs.append((net.forward, net.layout, net))
         else:
-            evs.append((_host_evaluator(m), N.AZ_FEAT_F32_NCHW))
+            evs.append((_host_evaluator(m), N.AZ_FEAT_F32_NCHW, None))
     a_black = np.asarray(colours, bool)
     result = np.zeros(G, np.int64)
     live = np.ones(G, bool)
@@ -468,10 +468,10 @@ def _arena_results(model_a, model_b, cfg, colours):
             break
         a_turn = (info[:, 0] == BLACK) == a_black
         actions = np.full(G, -1, np.int32)
-        for side, (ev, layout) in enumerate(evs):
+        for side, (ev, layout, net) in enumerate(evs):
             mask = live & (a_turn if side == 0 else ~a_turn)
             if mask.any():
-                visits, _ = eng.run_search(ev, add_noise=False, enable=mask.astype(np.uint8), layout=layout)
+                visits, _ = eng.run_search(ev, add_noise=False, enable=mask.astype(np.uint8), layout=layout, native_net=net)
                 actions[mask] = visits.cpu().numpy()[mask].argmax(axis=1)
         eng.play(torch.from_numpy(actions))
     eng.close()

@@ -311,3 +311,26 @@ def test_mcts_run_from_worker_threads():
         assert g is not None and g[0].tobytes() == want[0].tobytes() and g[1] == want[1] and g[2] == want[2]
     nxt = st.play(divmod(want[1], 5))                       # the caller goes on with the state on its own thread
     assert nxt.move_count == 3 and nxt.to_play == st.to_play * -1
+
+
+def test_run_search_enqueued_without_round_trips_equals_stepwise():
+    """Engine.run_search with the fused bf16 network handle (what MCTS.run and the arena pass) enqueues all batches
+    of a search at once; visits and root values equal the batch-by-batch loop's, also with games sitting out."""
+    from alphazero_amd.engine import Engine
+    from alphazero_amd.model import AlphaZeroNet
+    from alphazero_amd import _native as N
+    torch.manual_seed(4)
+    dev = torch.device("cuda:0")
+    net = AlphaZeroNet(board_size=9, channels=64, num_blocks=2).eval().to(dev).native("bf16")
+    assert net.fused
+    eng = Engine(board_size=9, games=5, num_simulations=72, inference_batch_size=8, topk_expand=16)
+    rng = np.random.RandomState(3)
+    for _ in range(6):
+        legal = eng.legal_mask().cpu().numpy()[:, :-1]
+        eng.play(torch.tensor([int(rng.choice(np.nonzero(row)[0])) for row in legal], dtype=torch.int32))
+    for enable in (None, np.array([1, 0, 1, 1, 0], np.uint8)):
+        v0, r0 = eng.run_search(net.forward, enable=enable, layout=net.layout)
+        v1, r1 = eng.run_search(net.forward, enable=enable, layout=net.layout, native_net=net)
+        assert torch.equal(v0, v1) and torch.equal(r0, r1)
+        assert int(v1.sum()) == 72 * (5 if enable is None else int(enable.sum()))
+    eng.close()
