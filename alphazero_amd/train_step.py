@@ -71,29 +71,33 @@ class DataParallelTrainer:
             for p in model.state_dict().values():
                 broadcast_(self.dist, p.data if p.is_floating_point() else p, src=0, group=process_group)
 
-    def _allreduce_grads(self):
-        params = [p for p in self.model.parameters() if p.grad is not None]
-        if self._flat is None or self._flat.numel() != sum(p.numel() for p in params):
-            self._flat = torch.empty(sum(p.numel() for p in params), dtype=params[0].grad.dtype, device=params[0].device)
+    def _bind_flat_grads(self):
+        """All gradients live in one flat buffer (each p.grad is a view of its slice): the all-reduce takes the buffer
+        as it is, with no gather / scatter copies around it."""
+        params = [p for p in self.model.parameters() if p.requires_grad]
+        self._flat = torch.zeros(sum(p.numel() for p in params), dtype=params[0].dtype, device=params[0].device)
         off = 0
         for p in params:
             n = p.numel()
-            self._flat[off:off + n].copy_(p.grad.reshape(-1))
+            p.grad = self._flat[off:off + n].view_as(p)
             off += n
+
+    def _allreduce_grads(self):
         all_reduce_(self.dist, self._flat, group=self.group)
         self._flat.div_(self.world)
-        off = 0
-        for p in params:
-            n = p.numel()
-            p.grad.copy_(self._flat[off:off + n].view_as(p.grad))
-            off += n
 
     def step(self, states, target_policies, target_values):
         """One optimisation step on this rank's shard of the global batch (train.py:526-548)."""
         self.model.train()
         if self.smooth > 0.0:
             target_policies = target_policies * (1.0 - self.smooth) + (self.smooth / target_policies.shape[1])
-        self.opt.zero_grad(set_to_none=True)
+        if self.dist and self.world > 1:
+            if self._flat is None:
+                self._bind_flat_grads()
+            else:
+                self._flat.zero_()
+        else:
+            self.opt.zero_grad(set_to_none=True)
         with torch.autocast(device_type="cuda", enabled=self.amp):
             logits, values = self.model(states)
             loss, pl, vl = loss_terms(logits, values, target_policies, target_values, self.delta, self.ent)
