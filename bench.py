@@ -202,9 +202,12 @@ def main():
                                      "mostly the bf16 residual stream parked per workgroup between the two convolutions of a block",
                      "launches": int(launches), "avg_launch_ms": round(per_launch_ms, 4),
                      "avg_launch_ms_start_to_end": round(tower_ms_sum / max(1, launches), 4),
+                     "achieved_start_to_end": round((tower_rows * fl_pos) / (tower_ms_sum * 1e-3) / 1e12, 1) if tower_ms_sum > 0 else 0.0,
                      "timing": "HIP events around every tower launch on its stream; launches of different lanes overlap, so "
                                "achieved = FLOPs of all launches / length of the union of their intervals and avg_launch_ms = "
-                               "that length / launches; avg_launch_ms_start_to_end is the plain mean of (end - start)",
+                               "that length / launches; avg_launch_ms_start_to_end is the plain mean of (end - start) and "
+                               "achieved_start_to_end the rate it gives (a launch shares the CUs with the other lanes' launches for "
+                               "most of that time; --lanes 1 makes the two readings coincide)",
                      "rows_per_launch": round(tower_rows / max(1, launches), 1), "flop_per_position": fl_pos,
                      "tower_share_of_wall": round(tower_ms * 1e-3 / dt, 4)},
         "host_seconds": {"rng": round(c["t_host_rng"], 4), "policy": round(c["t_host_policy"], 4), "samples": round(c["t_samples"], 4)},
