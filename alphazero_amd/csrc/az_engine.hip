@@ -1017,22 +1017,29 @@ int az_engine_create(const az_config* c, az_engine** out) {
         az_engine_destroy(e);
         return AZ_ERR_HIP;
     }
-    HIP_TRY(hipMemcpy(zdev, zob.data(), zob.size() * 8, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(pdev, pbc.data(), pbc.size() * 8, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(sdev, sqn.data(), sqn.size() * 8, hipMemcpyHostToDevice));
+    // from here on a failing HIP call must release the engine before returning
+#define HIP_TRY_E(x)                                                                            \
+    do {                                                                                        \
+        hipError_t e_ = (x);                                                                    \
+        if (e_ != hipSuccess) {                                                                 \
+            az_engine_destroy(e);                                                               \
+            return fail(AZ_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_));            \
+        }                                                                                       \
+    } while (0)
+    HIP_TRY_E(hipMemcpy(zdev, zob.data(), zob.size() * 8, hipMemcpyHostToDevice));
+    HIP_TRY_E(hipMemcpy(pdev, pbc.data(), pbc.size() * 8, hipMemcpyHostToDevice));
+    HIP_TRY_E(hipMemcpy(sdev, sqn.data(), sqn.size() * 8, hipMemcpyHostToDevice));
     d.zob = zdev; d.pbc = pdev; d.sqn = sdev;
-    if (hipHostMalloc((void**)&e->ctl_host, 4 * sizeof(int)) != hipSuccess ||
-        hipHostMalloc((void**)&e->stats_host, 8 * sizeof(long long)) != hipSuccess) {
-        az_engine_destroy(e);
-        return fail(AZ_ERR_HIP, "hipHostMalloc failed");
-    }
-    HIP_TRY(hipMemset(d.ctl, 0, 4 * sizeof(int)));
-    HIP_TRY(hipMemset(d.stats, 0, 8 * sizeof(long long)));
-    HIP_TRY(hipMemset(d.gstats, 0, (size_t)d.G * 8 * sizeof(long long)));
-    *out = e;
+    HIP_TRY_E(hipHostMalloc((void**)&e->ctl_host, 4 * sizeof(int)));
+    HIP_TRY_E(hipHostMalloc((void**)&e->stats_host, 8 * sizeof(long long)));
+    HIP_TRY_E(hipMemset(d.ctl, 0, 4 * sizeof(int)));
+    HIP_TRY_E(hipMemset(d.stats, 0, 8 * sizeof(long long)));
+    HIP_TRY_E(hipMemset(d.gstats, 0, (size_t)d.G * 8 * sizeof(long long)));
     int rc = az_rules_reset(e, nullptr, nullptr);
-    if (rc != AZ_OK) { az_engine_destroy(e); *out = nullptr; return rc; }
-    HIP_TRY(hipStreamSynchronize(nullptr));
+    if (rc != AZ_OK) { az_engine_destroy(e); return rc; }
+    HIP_TRY_E(hipStreamSynchronize(nullptr));
+#undef HIP_TRY_E
+    *out = e;
     return AZ_OK;
 }
 

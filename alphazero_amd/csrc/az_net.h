@@ -30,7 +30,7 @@ bool layers_supported(const az_net_config& c);
 int layers_create(const az_net_config& c, const NetLayout& L, const float* params, LayerNet** out);
 void layers_destroy(LayerNet* m);
 int layers_chunk_boards(const LayerNet* m);
-int layers_tower(LayerNet* m, const uint16_t* feat, int boards, uint16_t* hq, hipStream_t st);
+int layers_tower(LayerNet* m, const uint16_t* feat, int boards, uint16_t* hq, hipStream_t st, const int* rows_dev = nullptr, int board_off = 0);
 
 // bf16 MFMA path (az_net_mfma.hip)
 struct MfmaNet;
@@ -43,5 +43,8 @@ int mfma_profile(MfmaNet* m, double* tower_ms, long long* launches, long long* r
 int mfma_profile_spans(MfmaNet* m, double* spans, long long cap, long long* count);
 int mfma_set_grid_limit(MfmaNet* m, int workgroups);
 int mfma_forward(MfmaNet* m, const void* feat_bf16_nhwc, int rows, const int* rows_dev, float* logits, float* values, hipStream_t st);
+int mfma_reserve(MfmaNet* m, int rows);
+int mfma_forward_static(MfmaNet* m, const void* feat_bf16_nhwc, int rows, float* logits, float* values, hipStream_t st);
+long long mfma_static_max_rows(const MfmaNet* m);
 
 }  // namespace az

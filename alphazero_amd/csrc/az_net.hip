@@ -261,6 +261,7 @@ static int ensure_scratch(az_net* net, int rows) {
     const az_net_config& c = net->cfg;
     const size_t np = (size_t)c.board_size * c.board_size, C = c.channels, q = C / 4;
     HIP_TRY(hipDeviceSynchronize());
+    net->scratch_rows = 0;   // nothing usable until every buffer below exists
     for (float** p : {&net->x, &net->h, &net->y, &net->scale, &net->p0, &net->p1, &net->v0, &net->v1}) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
@@ -316,6 +317,28 @@ int az_net_forward_indirect(az_net* net, const void* feat, const int32_t* rows_d
     if (net->cfg.precision != AZ_NET_BF16) return fail(AZ_ERR_ARG, "az_net_forward_indirect: bf16 networks only");
     if (max_rows <= 0) return AZ_OK;
     return mfma_forward(net->mfma, feat, max_rows, rows_dev, logits, values, (hipStream_t)stream_);
+}
+
+int az_net_reserve(az_net* net, int32_t rows) {
+    if (!net) return fail(AZ_ERR_ARG, "null network");
+    if (!net->loaded) return fail(AZ_ERR_STATE, "az_net_reserve before az_net_load");
+    if (rows < 1) return fail(AZ_ERR_ARG, "az_net_reserve: rows must be >= 1");
+    if (net->cfg.precision == AZ_NET_BF16) return mfma_reserve(net->mfma, rows);
+    HIP_TRY(hipSetDevice(net->cfg.device));
+    return ensure_scratch(net, rows);
+}
+
+int az_net_forward_static(az_net* net, const void* feat, int32_t rows, float* logits, float* values, void* stream_) {
+    if (!net || !feat || !logits || !values) return fail(AZ_ERR_ARG, "null argument");
+    if (!net->loaded) return fail(AZ_ERR_STATE, "az_net_forward_static before az_net_load");
+    if (net->cfg.precision != AZ_NET_BF16) return fail(AZ_ERR_ARG, "az_net_forward_static: bf16 networks only");
+    if (rows <= 0) return AZ_OK;
+    return mfma_forward_static(net->mfma, feat, rows, logits, values, (hipStream_t)stream_);
+}
+
+int64_t az_net_static_max_rows(const az_net* net) {
+    if (!net || !net->loaded || net->cfg.precision != AZ_NET_BF16) return 0;
+    return mfma_static_max_rows(net->mfma);
 }
 
 int az_net_forward(az_net* net, const void* feat, int32_t rows, float* logits, float* values, void* stream_) {

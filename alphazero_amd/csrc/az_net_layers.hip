@@ -29,13 +29,23 @@ struct ConvArgs {
     char* out;             // [rows][out_stride bytes] bf16
     int out_stride, rows, n, np, ntaps, relu;
     int col_blocks;        // k_conv3_slab: blocks of NCOLS output channels (1-D grid, see slab_block)
+    const int* rows_dev;   // if set: the batch's board count lives here; this launch covers boards board_off .. of it,
+    int board_off;         // at most rows / np of them (rows is then the upper bound the grid was sized for)
 };
+
+// Rows this launch really has: all `rows` of them, or what the device-side board count leaves for its chunk.
+__device__ __forceinline__ int live_rows(int rows, int np, const int* rows_dev, int board_off) {
+    if (!rows_dev) return rows;
+    return max(0, min(rows, (*rows_dev - board_off) * np));
+}
 
 template <int KPT, int NCOLS, int WM, int WN>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_conv_layer(ConvArgs a) {
     constexpr int MI = 256 / (WM * 16), NI = NCOLS / (WN * 16);
     static_assert(NI % 2 == 0, "channel tiles are stored in pairs");
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    a.rows = live_rows(a.rows, a.np, a.rows_dev, a.board_off);
+    if ((int)blockIdx.x * 256 >= a.rows) return;   // whole workgroup, before any barrier
     TileGeo g;
     g.row0 = blockIdx.x * 256; g.n = a.n; g.np = a.np; g.vrows = a.rows; g.recip_np = 0; g.recip_n = 0;
     f32x4 acc[MI][NI];
@@ -86,6 +96,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_conv3_slab(Conv
     char* zreg = smem + 2 * kSlabBytes;        // 1 KiB of zeros, 256-byte aligned (kSlabBytes is a multiple of 256)
     char* bbuf = zreg + 1024;                  // two weight tiles
     AZ_LANE_GEO(MI, NI, WN);
+    a.rows = live_rows(a.rows, a.np, a.rows_dev, a.board_off);
     const int n = a.n, np = a.np, halo = n + 1, srows = 256 + 2 * halo;
     // 1-D grid; workgroups are dealt round-robin over the 8 XCDs, so ids 8 apart share an L2: the column blocks of one
     // row tile get ids 8 apart and fetch the tile's activations into one L2 instead of one L2 each
@@ -242,7 +253,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_conv3_slab(Conv
 }
 
 // [rows][32] bf16 feature rows -> [rows][64] (upper half zero): the stem then runs through the same tile loop.
-__global__ __launch_bounds__(256) void k_pad_features(const uint4* __restrict__ in, uint4* __restrict__ out, int rows) {
+__global__ __launch_bounds__(256) void k_pad_features(const uint4* __restrict__ in, uint4* __restrict__ out, int rows, int np,
+                                                      const int* rows_dev, int board_off) {
+    rows = live_rows(rows, np, rows_dev, board_off);
     const int i = blockIdx.x * 256 + threadIdx.x;   // one 16-byte piece of an output row (8 per row)
     if (i >= rows * 8) return;
     const int row = i >> 3, part = i & 7;
@@ -256,8 +269,9 @@ __global__ __launch_bounds__(256) void k_pad_features(const uint4* __restrict__ 
 // depend on where the board sits in the batch.
 __global__ __launch_bounds__(256) void k_se_gate_layer(const uint16_t* __restrict__ y, int np, int C, int hid, const float* __restrict__ w1,
                                                        const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2,
-                                                       float* __restrict__ gate) {
+                                                       float* __restrict__ gate, const int* rows_dev, int board_off) {
     extern __shared__ float sh[];   // partial [phases][C], pooled [C], hidden [hid]
+    if (rows_dev && (int)blockIdx.x >= *rows_dev - board_off) return;   // whole workgroup, before any barrier
     const int groups = C / 8, phases = 256 / groups;   // C in {64,128,192,256}: 8..32 groups; 192 -> 24 groups, 10 phases
     float* partial = sh;
     float* pooled = partial + phases * C;
@@ -325,7 +339,8 @@ __global__ __launch_bounds__(256) void k_se_gate_layer(const uint16_t* __restric
 
 // x <- relu(y * gate + x) (model.py:38-40), 8 channels per thread; gate == nullptr: no squeeze-excite.
 __global__ __launch_bounds__(256) void k_scale_residual(const uint4* __restrict__ y, const float* __restrict__ gate, uint4* __restrict__ x,
-                                                        int rows, int np, int C) {
+                                                        int rows, int np, int C, const int* rows_dev, int board_off) {
+    rows = live_rows(rows, np, rows_dev, board_off);
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     const int per_row = C / 8;
     if (i >= (size_t)rows * per_row) return;
@@ -508,8 +523,9 @@ static int launch_slab(const ConvArgs& a, int cout, hipStream_t st) {
 
 // Tower convolutions: 4x2 waves of 64 positions x NCOLS/2 channels. Heads: 8x1 waves of 32 positions x all channels.
 static int launch_conv(const PackedConv& pc, const char* in, int zero_off, char* out, int out_stride, int rows, int n, int relu, bool head,
-                       hipStream_t st) {
+                       hipStream_t st, const int* rows_dev, int board_off) {
     ConvArgs a;
+    a.rows_dev = rows_dev; a.board_off = board_off;
     a.in = in; a.in_stride = pc.cin_pad * 2; a.zero_off = zero_off; a.w = pc.w; a.w_block_vecs = pc.block_vecs; a.bias = pc.b;
     a.out = out; a.out_stride = out_stride; a.rows = rows; a.n = n; a.np = n * n; a.ntaps = pc.taps; a.relu = relu; a.col_blocks = 1;
     const int key = (pc.cin_pad / 32) * 1000 + pc.ncols;
@@ -544,30 +560,32 @@ static int launch_conv(const PackedConv& pc, const char* in, int zero_off, char*
 }
 
 // Boards [0, boards) of `feat` ([boards][np][32] bf16) -> hq [boards][np][2q] bf16; boards <= chunk_boards.
-int layers_tower(LayerNet* m, const uint16_t* feat, int boards, uint16_t* hq, hipStream_t st) {
+// rows_dev != null: `feat` is the chunk that starts at board `board_off` of a batch whose board count is *rows_dev on the
+// device; the grids are sized for `boards` and the workgroups past the live boards of the chunk leave at once.
+int layers_tower(LayerNet* m, const uint16_t* feat, int boards, uint16_t* hq, hipStream_t st, const int* rows_dev, int board_off) {
     const az_net_config& c = m->cfg;
     const int C = c.channels, n = c.board_size, np = m->np, rows = boards * np;
     if (boards <= 0) return AZ_OK;
     if (boards > m->chunk_boards) return fail(AZ_ERR_ARG, "layers_tower: chunk too large");
-    hipLaunchKernelGGL(k_pad_features, dim3((rows * 8 + 255) / 256), dim3(256), 0, st, (const uint4*)feat, (uint4*)m->f64, rows);
-    int rc = launch_conv(m->stem, m->f64, (int)m->zero_off_f, m->x, C * 2, rows, n, 1, false, st);
+    hipLaunchKernelGGL(k_pad_features, dim3((rows * 8 + 255) / 256), dim3(256), 0, st, (const uint4*)feat, (uint4*)m->f64, rows, np, rows_dev, board_off);
+    int rc = launch_conv(m->stem, m->f64, (int)m->zero_off_f, m->x, C * 2, rows, n, 1, false, st, rows_dev, board_off);
     if (rc != AZ_OK) return rc;
     const int per_row = C / 8;
     const dim3 egrid((unsigned)(((size_t)rows * per_row + 255) / 256));
     for (int i = 0; i < c.blocks; ++i) {
-        rc = launch_conv(m->convs[2 * i], m->x, (int)m->zero_off_c, m->h, C * 2, rows, n, 1, false, st);
+        rc = launch_conv(m->convs[2 * i], m->x, (int)m->zero_off_c, m->h, C * 2, rows, n, 1, false, st, rows_dev, board_off);
         if (rc != AZ_OK) return rc;
-        rc = launch_conv(m->convs[2 * i + 1], m->h, (int)m->zero_off_c, m->y, C * 2, rows, n, 0, false, st);
+        rc = launch_conv(m->convs[2 * i + 1], m->h, (int)m->zero_off_c, m->y, C * 2, rows, n, 0, false, st, rows_dev, board_off);
         if (rc != AZ_OK) return rc;
         const float* gate = nullptr;
         if (c.use_se) {
             hipLaunchKernelGGL(k_se_gate_layer, dim3(boards), dim3(256), ((size_t)(256 / (C / 8)) * C + C + c.se_hidden) * 4, st, (const uint16_t*)m->y, np, C, c.se_hidden,
-                               m->se[4 * i], m->se[4 * i + 1], m->se[4 * i + 2], m->se[4 * i + 3], m->gate);
+                               m->se[4 * i], m->se[4 * i + 1], m->se[4 * i + 2], m->se[4 * i + 3], m->gate, rows_dev, board_off);
             gate = m->gate;
         }
-        hipLaunchKernelGGL(k_scale_residual, egrid, dim3(256), 0, st, (const uint4*)m->y, gate, (uint4*)m->x, rows, np, C);
+        hipLaunchKernelGGL(k_scale_residual, egrid, dim3(256), 0, st, (const uint4*)m->y, gate, (uint4*)m->x, rows, np, C, rows_dev, board_off);
     }
-    rc = launch_conv(m->head, m->x, (int)m->zero_off_c, (char*)hq, 2 * m->q * 2, rows, n, 1, true, st);
+    rc = launch_conv(m->head, m->x, (int)m->zero_off_c, (char*)hq, 2 * m->q * 2, rows, n, 1, true, st, rows_dev, board_off);
     if (rc != AZ_OK) return rc;
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return fail(AZ_ERR_HIP, std::string("bf16 layer path: ") + hipGetErrorString(err));

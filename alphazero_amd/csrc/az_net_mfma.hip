@@ -23,6 +23,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -442,9 +443,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_tower(TowerPara
 template <int RB>
 __global__ __launch_bounds__(256) void k_policy_tail(const uint16_t* __restrict__ hq, const float* __restrict__ w3, const float* __restrict__ b3,
                                                      const float* __restrict__ wfcT, const float* __restrict__ bfc, float* __restrict__ logits,
-                                                     int rows, int np, int q, const int* rows_dev) {
+                                                     int rows, int np, int q, const int* rows_dev, int row_off) {
     extern __shared__ float flat[];  // [RB][2*np]
-    if (rows_dev) rows = min(rows, *rows_dev);
+    if (rows_dev) rows = min(rows, *rows_dev - row_off);   // this launch covers rows row_off .. of the batch
     const int r0 = blockIdx.x * RB, A = np + 1, q2 = 2 * q, F = 2 * np;
     const int nbk = min(RB, rows - r0);
     if (nbk <= 0) return;
@@ -500,9 +501,9 @@ __global__ __launch_bounds__(256) void k_policy_tail(const uint16_t* __restrict_
 template <int RB>
 __global__ __launch_bounds__(256) void k_value_tail(const uint16_t* __restrict__ hq, const uint16_t* __restrict__ w4T, const float* __restrict__ b4,
                                                     const float* __restrict__ w6, const float* __restrict__ b6, float* __restrict__ values,
-                                                    int rows, int np, int q, int vh, const int* rows_dev) {
+                                                    int rows, int np, int q, int vh, const int* rows_dev, int row_off) {
     extern __shared__ float v0[];  // [RB][q*np] then [RB][vh]
-    if (rows_dev) rows = min(rows, *rows_dev);
+    if (rows_dev) rows = min(rows, *rows_dev - row_off);
     const int r0 = blockIdx.x * RB, nbk = min(RB, rows - r0), K = q * np, q2 = 2 * q;
     if (nbk <= 0) return;
     float* hid = v0 + RB * K;
@@ -542,9 +543,9 @@ __global__ __launch_bounds__(256) void k_value_tail(const uint16_t* __restrict__
 template <int NTW>
 __global__ __launch_bounds__(256) void k_value_tail_mfma(const uint16_t* __restrict__ hq, const uint4* __restrict__ w4p, const float* __restrict__ b4p,
                                                          const float* __restrict__ w6p, const float* __restrict__ b6, float* __restrict__ values,
-                                                         int rows, int np, int q, int nks, int ntiles, unsigned recip_qc, const int* rows_dev, float* part_out, int part_stride) {
+                                                         int rows, int np, int q, int nks, int ntiles, unsigned recip_qc, const int* rows_dev, int row_off, float* part_out, int part_stride) {
     __shared__ float red[4][16];
-    if (rows_dev) rows = min(rows, *rows_dev);
+    if (rows_dev) rows = min(rows, *rows_dev - row_off);
     const int r0 = blockIdx.x * 16;
     if (r0 >= rows) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, kq = lane >> 4;
@@ -625,8 +626,8 @@ __global__ __launch_bounds__(256) void k_value_tail_mfma(const uint16_t* __restr
 
 // Second half of a split value tail: value = tanh(sum of the workgroups' shares in index order + b6).
 __global__ __launch_bounds__(256) void k_value_finish(const float* __restrict__ part, int shares, const float* __restrict__ b6, float* __restrict__ values,
-                                                      int rows, const int* rows_dev) {
-    if (rows_dev) rows = min(rows, *rows_dev);
+                                                      int rows, const int* rows_dev, int row_off) {
+    if (rows_dev) rows = min(rows, *rows_dev - row_off);
     const int r = blockIdx.x * 256 + threadIdx.x;
     if (r >= rows) return;
     float s = 0.f;
@@ -651,6 +652,8 @@ struct MfmaNet {
     float* vpart = nullptr;       // split value tail: [chunk rows][shares] partial sums, allocated with hq (layer path, large boards)
     uint4* xres = nullptr;   // residual-stream scratch for max_grid workgroups
     int max_grid = 0;
+    std::vector<void*> retired;   // scratch buffers that were replaced by larger ones: launches already enqueued may still use
+                                  // them, so they are only freed with the network (sizes grow geometrically: bounded waste)
     int split = 0;                // 0: 4x2 waves, weights through LDS; 1: 2x4 waves, weight fragments from global memory (C = 192)
     LayerNet* layers = nullptr;   // set instead of the fused tower's weights when the shape needs the layer-by-layer path
     // optional timing of the tower kernel with HIP events on the launch stream
@@ -853,8 +856,36 @@ int mfma_create(const az_net_config& c, const NetLayout& L, const float* Pm, Mfm
         if (hipGetDeviceProperties(&prop, c.device) != hipSuccess) { mfma_destroy(m); return fail(AZ_ERR_HIP, "hipGetDeviceProperties"); }
         m->max_grid = std::max(1, prop.multiProcessorCount);
         if (hipMalloc((void**)&m->xres, (size_t)m->max_grid * 256 * (size_t)C * 2) != hipSuccess) { mfma_destroy(m); return fail(AZ_ERR_HIP, "hipMalloc (residual scratch)"); }
+    } else {   // layer path: head activations (and value-tail shares) of one chunk, sized once
+        int rcr = mfma_reserve(m, layers_chunk_boards(m->layers));
+        if (rcr != AZ_OK) { mfma_destroy(m); return rcr; }
     }
     *out = m;
+    return AZ_OK;
+}
+
+// Scratch for forwards of up to `rows` positions, so that later forwards of that size allocate nothing. Never waits for
+// the device and never frees a buffer a launch in flight may use (see MfmaNet::retired).
+int mfma_reserve(MfmaNet* m, int rows) {
+    if (rows < 1) return fail(AZ_ERR_ARG, "az_net_reserve: rows must be >= 1");
+    if (hipSetDevice(m->cfg.device) != hipSuccess) return fail(AZ_ERR_HIP, "hipSetDevice");
+    const int np = m->cfg.board_size * m->cfg.board_size;
+    if (m->layers) rows = std::min(rows, layers_chunk_boards(m->layers));   // larger batches run chunk by chunk
+    if (rows <= m->hq_rows) return AZ_OK;
+    uint16_t* h = nullptr;
+    if (hipMalloc((void**)&h, (size_t)rows * np * 2 * m->q * 2) != hipSuccess) return fail(AZ_ERR_HIP, "hipMalloc (head scratch)");
+    float* vp = nullptr;
+    if (m->layers && np > 81 && m->w4p && m->v_ntiles > 4) {   // split value tail (run_tails)
+        if (hipMalloc((void**)&vp, (size_t)(rows + 16) * ((m->v_ntiles + 3) / 4) * sizeof(float)) != hipSuccess) {
+            (void)hipFree(h);
+            return fail(AZ_ERR_HIP, "hipMalloc (value tail scratch)");
+        }
+    }
+    if (m->hq) m->retired.push_back(m->hq);
+    if (vp && m->vpart) m->retired.push_back(m->vpart);
+    m->hq = h;
+    if (vp) m->vpart = vp;
+    m->hq_rows = rows;
     return AZ_OK;
 }
 
@@ -878,10 +909,10 @@ int mfma_set_grid_limit(MfmaNet* m, int workgroups) {
     if (workgroups < 1) return fail(AZ_ERR_ARG, "workgroup limit must be >= 1");
     if (m->layers) return AZ_OK;   // the layer path has no resident workgroups
     if (workgroups == m->max_grid) return AZ_OK;
-    if (hipDeviceSynchronize() != hipSuccess) return fail(AZ_ERR_HIP, "hipDeviceSynchronize");
+    if (hipSetDevice(m->cfg.device) != hipSuccess) return fail(AZ_ERR_HIP, "hipSetDevice");
     uint4* x = nullptr;
     if (hipMalloc((void**)&x, (size_t)workgroups * 256 * (size_t)m->cfg.channels * 2) != hipSuccess) return fail(AZ_ERR_HIP, "hipMalloc (residual scratch)");
-    if (m->xres) (void)hipFree(m->xres);
+    if (m->xres) m->retired.push_back(m->xres);
     m->xres = x;
     m->max_grid = workgroups;
     return AZ_OK;
@@ -936,22 +967,23 @@ void mfma_destroy(MfmaNet* m) {
     if (m->hq) (void)hipFree(m->hq);
     if (m->vpart) (void)hipFree(m->vpart);
     if (m->xres) (void)hipFree(m->xres);
+    for (void* p : m->retired) (void)hipFree(p);
     if (m->layers) layers_destroy(m->layers);
     delete m;
 }
 
 // Policy and value tails over the head activations hq [rows][np][2q].
-static void run_tails(MfmaNet* m, const uint16_t* hq_in, int rows, const int* rows_dev, float* logits, float* values, hipStream_t st) {
+static void run_tails(MfmaNet* m, const uint16_t* hq_in, int rows, const int* rows_dev, int row_off, float* logits, float* values, hipStream_t st) {
     const az_net_config& c = m->cfg;
     const int np = c.board_size * c.board_size, q = m->q;
     // boards per workgroup by board size only (a board's sums run in the same order either way): large boards come in
     // chunks of a few hundred rows, which 8 per workgroup would spread over too few CUs
     if (np <= 81)
         hipLaunchKernelGGL((k_policy_tail<8>), dim3((rows + 7) / 8), dim3(256), (size_t)8 * 2 * np * 4, st, hq_in, m->w3, m->b3, m->wfcT, m->bfc, logits, rows,
-                           np, q, rows_dev);
+                           np, q, rows_dev, row_off);
     else
         hipLaunchKernelGGL((k_policy_tail<2>), dim3((rows + 1) / 2), dim3(256), (size_t)2 * 2 * np * 4, st, hq_in, m->w3, m->b3, m->wfcT, m->bfc, logits, rows,
-                           np, q, rows_dev);
+                           np, q, rows_dev, row_off);
     if (m->w4p) {
         const dim3 vg((rows + 15) / 16);
         const uint4* wp = (const uint4*)m->w4p;
@@ -960,82 +992,52 @@ static void run_tails(MfmaNet* m, const uint16_t* hq_in, int rows, const int* ro
             // large boards (long K, chunks of a few hundred rows): the unit tiles are dealt to `shares` workgroups per 16
             // boards, one tile per wave, and a second kernel adds the shares in index order. Chosen by shape only.
             hipLaunchKernelGGL((k_value_tail_mfma<1>), dim3(vg.x, shares), dim3(256), 0, st, hq_in, wp, m->b4p, m->w6p, m->b6, values, rows, np, q, m->v_nks,
-                               m->v_ntiles, m->v_recip, rows_dev, m->vpart, shares);
-            hipLaunchKernelGGL(k_value_finish, dim3((rows + 255) / 256), dim3(256), 0, st, (const float*)m->vpart, shares, m->b6, values, rows, rows_dev);
+                               m->v_ntiles, m->v_recip, rows_dev, row_off, m->vpart, shares);
+            hipLaunchKernelGGL(k_value_finish, dim3((rows + 255) / 256), dim3(256), 0, st, (const float*)m->vpart, shares, m->b6, values, rows, rows_dev, row_off);
             return;
         }
         switch (shares) {
-            case 1: hipLaunchKernelGGL((k_value_tail_mfma<1>), vg, dim3(256), 0, st, hq_in, wp, m->b4p, m->w6p, m->b6, values, rows, np, q, m->v_nks, m->v_ntiles, m->v_recip, rows_dev, (float*)nullptr, 0); break;
-            case 2: hipLaunchKernelGGL((k_value_tail_mfma<2>), vg, dim3(256), 0, st, hq_in, wp, m->b4p, m->w6p, m->b6, values, rows, np, q, m->v_nks, m->v_ntiles, m->v_recip, rows_dev, (float*)nullptr, 0); break;
-            case 3: hipLaunchKernelGGL((k_value_tail_mfma<3>), vg, dim3(256), 0, st, hq_in, wp, m->b4p, m->w6p, m->b6, values, rows, np, q, m->v_nks, m->v_ntiles, m->v_recip, rows_dev, (float*)nullptr, 0); break;
-            default: hipLaunchKernelGGL((k_value_tail_mfma<4>), vg, dim3(256), 0, st, hq_in, wp, m->b4p, m->w6p, m->b6, values, rows, np, q, m->v_nks, m->v_ntiles, m->v_recip, rows_dev, (float*)nullptr, 0); break;
+            case 1: hipLaunchKernelGGL((k_value_tail_mfma<1>), vg, dim3(256), 0, st, hq_in, wp, m->b4p, m->w6p, m->b6, values, rows, np, q, m->v_nks, m->v_ntiles, m->v_recip, rows_dev, row_off, (float*)nullptr, 0); break;
+            case 2: hipLaunchKernelGGL((k_value_tail_mfma<2>), vg, dim3(256), 0, st, hq_in, wp, m->b4p, m->w6p, m->b6, values, rows, np, q, m->v_nks, m->v_ntiles, m->v_recip, rows_dev, row_off, (float*)nullptr, 0); break;
+            case 3: hipLaunchKernelGGL((k_value_tail_mfma<3>), vg, dim3(256), 0, st, hq_in, wp, m->b4p, m->w6p, m->b6, values, rows, np, q, m->v_nks, m->v_ntiles, m->v_recip, rows_dev, row_off, (float*)nullptr, 0); break;
+            default: hipLaunchKernelGGL((k_value_tail_mfma<4>), vg, dim3(256), 0, st, hq_in, wp, m->b4p, m->w6p, m->b6, values, rows, np, q, m->v_nks, m->v_ntiles, m->v_recip, rows_dev, row_off, (float*)nullptr, 0); break;
         }
     } else {
         const size_t vt = ((size_t)4 * q * np + 4 * c.value_hidden) * 4;
         hipLaunchKernelGGL((k_value_tail<4>), dim3((rows + 3) / 4), dim3(256), vt, st, hq_in, m->w4T, m->b4, m->w6, m->b6, values, rows, np, q,
-                           c.value_hidden, rows_dev);
+                           c.value_hidden, rows_dev, row_off);
     }
 }
 
-int mfma_forward(MfmaNet* m, const void* feat, int rows, const int* rows_dev, float* logits, float* values, hipStream_t st) {
+// A timed launch's event pair (null when profiling is off).
+static int prof_begin(MfmaNet* m, long long rows, hipStream_t st, std::pair<hipEvent_t, hipEvent_t>** out) {
+    *out = nullptr;
+    if (!m->profiling) return AZ_OK;
+    if (m->ev_used == m->events.size()) {
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return fail(AZ_ERR_HIP, "hipEventCreate");
+        m->events.emplace_back(a, b);
+    }
+    *out = &m->events[m->ev_used++];
+    m->prof_rows += rows;
+    (void)hipEventRecord((*out)->first, st);
+    return AZ_OK;
+}
+
+// Fused tower + tails with the given scratch (head activations for `rows` rows, residual stream for `grid_cap` workgroups).
+static int fused_forward(MfmaNet* m, const void* feat, int rows, const int* rows_dev, float* logits, float* values, hipStream_t st,
+                         uint16_t* hq, uint4* xres, int grid_cap, bool timed) {
     const az_net_config& c = m->cfg;
-    const int C = c.channels, np = c.board_size * c.board_size, q = m->q;
-    if (m->layers) {
-        if (rows_dev) return fail(AZ_ERR_STATE, "az_net_forward_indirect: not available for networks on the layer-by-layer path");
-        const int chunk = layers_chunk_boards(m->layers), A = np + 1;
-        if (m->hq_rows < chunk) {
-            if (hipDeviceSynchronize() != hipSuccess) return fail(AZ_ERR_HIP, "hipDeviceSynchronize");
-            if (m->hq) (void)hipFree(m->hq);
-            m->hq = nullptr;
-            if (hipMalloc((void**)&m->hq, (size_t)chunk * np * 2 * q * 2) != hipSuccess) return fail(AZ_ERR_HIP, "hipMalloc (head scratch)");
-            m->hq_rows = chunk;
-            if (np > 81 && m->w4p && m->v_ntiles > 4) {   // split value tail (run_tails)
-                if (m->vpart) (void)hipFree(m->vpart);
-                m->vpart = nullptr;
-                if (hipMalloc((void**)&m->vpart, (size_t)(chunk + 16) * ((m->v_ntiles + 3) / 4) * sizeof(float)) != hipSuccess)
-                    return fail(AZ_ERR_HIP, "hipMalloc (value tail scratch)");
-            }
-        }
-        std::pair<hipEvent_t, hipEvent_t>* evl = nullptr;
-        if (m->profiling) {
-            if (m->ev_used == m->events.size()) {
-                hipEvent_t a, b;
-                if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return fail(AZ_ERR_HIP, "hipEventCreate");
-                m->events.emplace_back(a, b);
-            }
-            evl = &m->events[m->ev_used++];
-            m->prof_rows += rows;
-            (void)hipEventRecord(evl->first, st);
-        }
-        const int nchunks = (rows + chunk - 1) / chunk, per = (rows + nchunks - 1) / nchunks;   // even shares: no small last chunk
-        for (int off = 0; off < rows; off += per) {
-            const int nb = std::min(per, rows - off);
-            int rc = layers_tower(m->layers, (const uint16_t*)feat + (size_t)off * np * 32, nb, m->hq, st);
-            if (rc != AZ_OK) return rc;
-            run_tails(m, m->hq, nb, nullptr, logits + (size_t)off * A, values + off, st);
-        }
-        if (evl) (void)hipEventRecord(evl->second, st);
-        hipError_t errl = hipGetLastError();
-        if (errl != hipSuccess) return fail(AZ_ERR_HIP, std::string("bf16 forward (layers): ") + hipGetErrorString(errl));
-        return AZ_OK;
-    }
-    if (rows > m->hq_rows) {  // scratch for the head activations grows outside the steady state
-        if (hipDeviceSynchronize() != hipSuccess) return fail(AZ_ERR_HIP, "hipDeviceSynchronize");
-        if (m->hq) (void)hipFree(m->hq);
-        m->hq = nullptr;
-        const int cap = rows + rows / 4 + 16;
-        if (hipMalloc((void**)&m->hq, (size_t)cap * np * 2 * q * 2) != hipSuccess) return fail(AZ_ERR_HIP, "hipMalloc (head scratch)");
-        m->hq_rows = cap;
-    }
+    const int C = c.channels;
     TowerParams P = m->P;
     P.rows = rows;
     P.feat = (const uint16_t*)feat;
-    P.hq = m->hq;
+    P.hq = hq;
     P.stamps = nullptr;
-    P.xres = m->xres;
+    P.xres = xres;
     P.items = (rows + m->TB - 1) / m->TB;
     P.rows_dev = rows_dev;
-    const int grid = std::min(P.items, m->max_grid);
+    const int grid = std::min(P.items, grid_cap);
 #ifdef AZ_STAMP
     static unsigned long long* stamp_dev = nullptr;
     static int stamp_grid = 0;
@@ -1048,15 +1050,9 @@ int mfma_forward(MfmaNet* m, const void* feat, int rows, const int* rows_dev, fl
 #endif
     const size_t lds = tower_lds_bytes(C, m->NH, m->TB, c.se_hidden);
     std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
-    if (m->profiling) {
-        if (m->ev_used == m->events.size()) {
-            hipEvent_t a, b;
-            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return fail(AZ_ERR_HIP, "hipEventCreate");
-            m->events.emplace_back(a, b);
-        }
-        ev = &m->events[m->ev_used++];
-        m->prof_rows += rows_dev ? 0 : rows;   // indirect launches: the caller knows the row total
-        (void)hipEventRecord(ev->first, st);
+    if (timed) {
+        int rcp = prof_begin(m, rows_dev ? 0 : rows, st, &ev);   // indirect launches: the caller knows the row total
+        if (rcp != AZ_OK) return rcp;
     }
     switch (C) {
         case 32: hipLaunchKernelGGL((k_tower<32, 8, 1, 32>), dim3(grid), dim3(512), lds, st, P); break;
@@ -1075,7 +1071,7 @@ int mfma_forward(MfmaNet* m, const void* feat, int rows, const int* rows_dev, fl
         default: return fail(AZ_ERR_ARG, "unsupported channel count");
     }
     if (ev) (void)hipEventRecord(ev->second, st);
-    run_tails(m, m->hq, rows, rows_dev, logits, values, st);
+    run_tails(m, hq, rows, rows_dev, 0, logits, values, st);
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return fail(AZ_ERR_HIP, std::string("bf16 forward: ") + hipGetErrorString(err));
 #ifdef AZ_STAMP
@@ -1099,6 +1095,80 @@ int mfma_forward(MfmaNet* m, const void* feat, int rows, const int* rows_dev, fl
     }
 #endif
     return AZ_OK;
+}
+
+// rows_dev == null: `rows` positions. rows_dev != null: *rows_dev positions (read on the device, at most `rows`).
+int mfma_forward(MfmaNet* m, const void* feat, int rows, const int* rows_dev, float* logits, float* values, hipStream_t st) {
+    const az_net_config& c = m->cfg;
+    const int np = c.board_size * c.board_size;
+    if (m->layers) {
+        const int chunk = layers_chunk_boards(m->layers), A = np + 1;   // hq / vpart hold one chunk (mfma_create)
+        std::pair<hipEvent_t, hipEvent_t>* evl = nullptr;
+        int rcp = prof_begin(m, rows_dev ? 0 : rows, st, &evl);
+        if (rcp != AZ_OK) return rcp;
+        // direct: even shares, no small last chunk. indirect: whole chunks over the upper bound; the workgroups of a chunk
+        // past the device-side count leave at once, so a batch that fills one chunk pays for the others' empty launches only
+        const int nchunks = (rows + chunk - 1) / chunk, per = rows_dev ? chunk : (rows + nchunks - 1) / nchunks;
+        for (int off = 0; off < rows; off += per) {
+            const int nb = std::min(per, rows - off);
+            int rc = layers_tower(m->layers, (const uint16_t*)feat + (size_t)off * np * 32, nb, m->hq, st, rows_dev, off);
+            if (rc != AZ_OK) return rc;
+            run_tails(m, m->hq, nb, rows_dev, off, logits + (size_t)off * A, values + off, st);
+        }
+        if (evl) (void)hipEventRecord(evl->second, st);
+        hipError_t errl = hipGetLastError();
+        if (errl != hipSuccess) return fail(AZ_ERR_HIP, std::string("bf16 forward (layers): ") + hipGetErrorString(errl));
+        return AZ_OK;
+    }
+    if (rows > m->hq_rows) {   // first use, or a larger batch than any before: az_net_reserve avoids this in a steady state
+        int rc = mfma_reserve(m, rows + rows / 4 + 16);
+        if (rc != AZ_OK) return rc;
+    }
+    return fused_forward(m, feat, rows, rows_dev, logits, values, st, m->hq, m->xres, m->max_grid, true);
+}
+
+// ---- the entry point that allocates nothing: scratch in a device array of the library itself -----------------------
+// One array per GPU (every GPU the library runs on holds its copy until the process ends), shared by every network and
+// every call on that GPU: calls that overlap on one GPU race. Layout: residual-stream scratch for kStaticGrid workgroups,
+// then the head activations.
+constexpr size_t kStaticBytes = (size_t)64 << 20;
+constexpr int kStaticGrid = 256;
+static __device__ __align__(256) unsigned char scratch[kStaticBytes];
+static unsigned char* g_static_ptr[64];   // per device: the array's address on that device
+
+static int static_scratch(int device, unsigned char** out) {
+    if (device < 0 || device >= 64) return fail(AZ_ERR_ARG, "device index out of range");
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!g_static_ptr[device]) {
+        if (hipSetDevice(device) != hipSuccess) return fail(AZ_ERR_HIP, "hipSetDevice");
+        void* p = nullptr;
+        hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p) return fail(AZ_ERR_HIP, std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e));
+        g_static_ptr[device] = (unsigned char*)p;
+    }
+    *out = g_static_ptr[device];
+    return AZ_OK;
+}
+
+static size_t static_xres_bytes(const MfmaNet* m) { return (size_t)kStaticGrid * 256 * (size_t)m->cfg.channels * 2; }
+
+long long mfma_static_max_rows(const MfmaNet* m) {
+    if (m->layers) return 0;
+    const size_t np = (size_t)m->cfg.board_size * m->cfg.board_size;
+    return (long long)((kStaticBytes - static_xres_bytes(m)) / (np * 2 * m->q * 2));
+}
+
+int mfma_forward_static(MfmaNet* m, const void* feat, int rows, float* logits, float* values, hipStream_t st) {
+    if (m->layers) return fail(AZ_ERR_ARG, "az_net_forward_static: fused bf16 networks only (boards up to 9x9, up to 192 channels)");
+    const long long cap = mfma_static_max_rows(m);
+    if (rows > cap)
+        return fail(AZ_ERR_CAPACITY, "az_net_forward_static: " + std::to_string(rows) + " rows exceed the static scratch (at most " +
+                                         std::to_string(cap) + " rows for this network shape)");
+    unsigned char* base = nullptr;
+    int rc = static_scratch(m->cfg.device, &base);
+    if (rc != AZ_OK) return rc;
+    return fused_forward(m, feat, rows, nullptr, logits, values, st, (uint16_t*)(base + static_xres_bytes(m)), (uint4*)base, kStaticGrid, false);
 }
 
 }  // namespace az

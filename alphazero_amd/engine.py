@@ -227,8 +227,8 @@ class Engine:
         else:
             done = True
         if (not done and native_net is not None and capture_priors is None and layout == N.AZ_FEAT_BF16_NHWC
-                and getattr(native_net, "fused", False)):
-            # the fused bf16 network reads the row count on the device: all batches are enqueued without a round trip
+                and getattr(native_net, "indirect", False)):
+            # the bf16 network reads the row count on the device: all batches are enqueued without a round trip
             fb, lb, vb, rows_dev = self._async_buffers()
             self.set_async(True)
             try:

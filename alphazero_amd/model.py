@@ -110,6 +110,19 @@ class AlphaZeroNet(nn.Module):
         return ent[1]
 
 
+def _native_auto(self, device=None, shared: bool = True) -> "NativeNet":
+    """native("bf16") where the MFMA kernels cover the shape (channels 32/64/128/192 on boards up to 9x9; 64/128/192/256
+    with at most 32 input planes on boards up to 19x19), else native("f32"): every shape upstream's CLI accepts runs."""
+    try:
+        return self.native("bf16", device, shared)
+    except N.NativeError as e:
+        if "unsupported" not in str(e) and "LDS budget" not in str(e) and "too large" not in str(e):
+            raise
+        return self.native("f32", device, shared)
+
+
+AlphaZeroNet.native_auto = _native_auto
+
 PolicyValueNet = AlphaZeroNet  # name used in some descriptions of the upstream project
 
 
@@ -142,7 +155,8 @@ class NativeNet:
             N.check(self.L.az_net_load(h, p.ctypes.data_as(C.c_void_p), p.size), "az_net_load")
         f = C.c_int32()
         N.check(self.L.az_net_is_fused(h, C.byref(f)), "az_net_is_fused")
-        self.fused = bool(f.value)     # single fused tower kernel (forward_indirect available) vs layer by layer
+        self.fused = bool(f.value)     # single fused tower kernel vs layer by layer (larger boards, 256 channels) / float32
+        self.indirect = precision == "bf16"   # forward_indirect: the row count is read on the device
 
     def close(self):
         if getattr(self, "_h", None):
@@ -154,6 +168,26 @@ class NativeNet:
             self.close()
         except Exception:
             pass
+
+    def reserve(self, rows: int):
+        """Allocate the activation scratch for forwards of up to `rows` positions now: later forwards of that size
+        allocate nothing and never wait for the device."""
+        with torch.cuda.device(self.device):
+            N.check(self.L.az_net_reserve(self._h, int(rows)), "az_net_reserve")
+
+    def static_max_rows(self) -> int:
+        return int(self.L.az_net_static_max_rows(self._h))
+
+    def forward_static(self, feats: torch.Tensor, logits: torch.Tensor, values: torch.Tensor, rows: int | None = None):
+        """forward() into caller-provided float32 buffers with the library's own static device scratch: the call
+        allocates nothing (az_net_forward_static). Calls that overlap on one GPU share that scratch and race."""
+        rows = feats.shape[0] if rows is None else rows
+        assert feats.dtype == torch.bfloat16 and feats.is_contiguous() and feats.shape[0] >= rows
+        assert logits.dtype == torch.float32 and logits.is_contiguous() and logits.shape[0] >= rows
+        assert values.dtype == torch.float32 and values.is_contiguous() and values.shape[0] >= rows
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        N.check(self.L.az_net_forward_static(self._h, C.c_void_p(feats.data_ptr()), rows, C.c_void_p(logits.data_ptr()),
+                                             C.c_void_p(values.data_ptr()), st), "az_net_forward_static")
 
     def forward(self, feats: torch.Tensor, rows: int | None = None):
         """feats: device tensor in this precision's layout (bf16 [rows, n*n, cpad] or f32 [rows, C, n, n])."""

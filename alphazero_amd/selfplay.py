@@ -157,7 +157,11 @@ class _Lane:
                               inference_batch_size=cfg.mcts_inference_batch, topk_expand=cfg.mcts_topk_expand,
                               virtual_loss=cfg.mcts_virtual_loss, dedup_leaves=dedup_leaves, device=self.dev)
             if hasattr(model, "native"):
-                self.net = model.native(precision, self.dev, shared=not own_stream)
+                if precision == "bf16":      # shapes the MFMA kernels do not cover run on the float32 kernels
+                    self.net = model.native_auto(self.dev, shared=not own_stream)
+                    precision = self.net.precision
+                else:
+                    self.net = model.native(precision, self.dev, shared=not own_stream)
                 self.layout = self.net.layout
                 self.eval = self.net.forward
             else:  # plain callable on device tensors: feats f32 NCHW -> (logits, values)
@@ -175,7 +179,9 @@ class _Lane:
             if self.root_reuse:
                 self.eng.set_root_reuse(True)
             # with the native bf16 network the batches of a search are enqueued without host round trips
-            self.async_search = self.net is not None and precision == "bf16" and self.net.fused
+            self.async_search = self.net is not None and precision == "bf16" and self.net.indirect
+            if self.net is not None and precision == "bf16":
+                self.net.reserve(self.max_rows)      # no allocation inside the move loop
             if self.async_search:
                 self.eng.set_async(True)
                 self.rows_dev = self.eng.rows_device()
@@ -382,7 +388,7 @@ class BatchedSelfPlay:
                       for i, g in enumerate(share)]
         if tower_workgroups is not None:
             for ln in self.lanes:
-                if ln.net is not None and precision == "bf16":
+                if ln.net is not None and ln.net.precision == "bf16":
                     ln.net.set_tower_workgroups(tower_workgroups)
         self.A = self.lanes[0].A
         self.num_games, self.next_id = 0, 0
@@ -397,7 +403,7 @@ class BatchedSelfPlay:
     def set_async(self, enable: bool):
         """Switch between enqueueing the batches of a search without host round trips and one round trip per batch."""
         for ln in self.lanes:
-            ok = bool(enable) and ln.net is not None and ln.layout == N.AZ_FEAT_BF16_NHWC and ln.net.fused
+            ok = bool(enable) and ln.net is not None and ln.layout == N.AZ_FEAT_BF16_NHWC and ln.net.indirect
             ln.async_search = ok
             ln.eng.set_async(ok)
 

@@ -383,12 +383,35 @@ def rank_share(games: int, rank: int, world: int):
     return first, (rank + 1) * games // world - first
 
 
+def selfplay_seed0(cfg, iter_idx: int) -> int:
+    """Seed of game 0 of an iteration; game j uses this + j. Upstream gives worker w the seed seed + iter*1000 + w
+    (train.py:446) with at most a few dozen workers; here j runs over all games of the iteration, so the stride between
+    iterations grows with the game count: up to 1000 games the seeds are upstream's, beyond that the iterations' seed
+    ranges still do not overlap (overlapping ranges would replay games bit for bit while the best model is unchanged)."""
+    return cfg.seed + iter_idx * max(1000, int(cfg.selfplay_games_per_iter))
+
+
+_warned_roots = False
+
+
+def _warn_root_parallelism(cfg, where: str):
+    """mcts_root_parallelism > 1 splits a search over several roots upstream (mcts.py:240-268); the lockstep engine
+    searches one root per game."""
+    global _warned_roots
+    if getattr(cfg, "mcts_root_parallelism", 1) > 1 and not _warned_roots:
+        _warned_roots = True
+        import warnings
+        warnings.warn(f"{where}: mcts_root_parallelism={cfg.mcts_root_parallelism} is ignored by the lockstep engine (one root per game); "
+                      "MCTS.run honours it", RuntimeWarning, stacklevel=3)
+
+
 def run_selfplay(best_model, cfg, iter_idx: int, pool=None, model_path=None, model_version: int = 0):
     """train.py:395-463 on the GPU: returns (samples, black_wins, white_wins, draws) for this rank's share of
     cfg.selfplay_games_per_iter games (all of them without torch.distributed). `pool`, `model_path` and
     `model_version` belong to upstream's worker processes and are accepted for call compatibility."""
     del pool, model_path, model_version
     from .selfplay import BatchedSelfPlay, SelfPlayConfig
+    _warn_root_parallelism(cfg, "run_selfplay")
     _, rank, world = _world()
     first, mine = rank_share(cfg.selfplay_games_per_iter, rank, world)
     if mine <= 0:
@@ -398,7 +421,7 @@ def run_selfplay(best_model, cfg, iter_idx: int, pool=None, model_path=None, mod
     slots = min(mine, cfg.lockstep_games if cfg.lockstep_games > 0 else 4096)
     lanes = cfg.selfplay_lanes if cfg.selfplay_lanes > 0 else (3 if slots >= 768 else 1)
     sp = BatchedSelfPlay(best_model if on_gpu else _host_evaluator(best_model), SelfPlayConfig.from_train_config(cfg), games=slots,
-                         seed0=cfg.seed + iter_idx * 1000 + first, dedup_leaves=not cfg.no_dedup_leaves, lanes=lanes,
+                         seed0=selfplay_seed0(cfg, iter_idx) + first, dedup_leaves=not cfg.no_dedup_leaves, lanes=lanes,
                          tower_workgroups=1024 if lanes > 1 else None)
     return sp.run(num_games=mine)
 
@@ -439,6 +462,7 @@ def _arena_results(model_a, model_b, cfg, colours):
     lockstep: each move, the games where A is to move are searched with A's network, the others with B's.
     Moves are the most visited child (first maximum), no noise (train.py:566-573)."""
     from .engine import Engine
+    _warn_root_parallelism(cfg, "arena")
     G = len(colours)
     n, A = cfg.board_size, cfg.board_size * cfg.board_size + 1
     eng = Engine(board_size=n, history_len=cfg.history_len, games=G, komi=cfg.komi, num_simulations=cfg.eval_simulations,
@@ -449,7 +473,7 @@ def _arena_results(model_a, model_b, cfg, colours):
     for m in (model_a, model_b):
         m.eval()
         if next(m.parameters()).is_cuda:
-            net = m.native("bf16", eng.device)
+            net = m.native_auto(eng.device)      # bf16 MFMA kernels, or the float32 kernels for shapes those do not cover
             evs.append((net.forward, net.layout, net))
         else:
             evs.append((_host_evaluator(m), N.AZ_FEAT_F32_NCHW, None))
@@ -493,16 +517,9 @@ def play_match(model_a, model_b, cfg, games: int):
     return out.count(1), out.count(-1), out.count(0)
 
 
-def _wilson_interval(successes: float, n: int, z: float = 1.96):
-    if n <= 0:
-        return 0.0, 1.0
-    p = successes / n
-    den = 1.0 + (z * z) / n
-    center = (p + (z * z) / (2 * n)) / den
-    margin = (z / den) * np.sqrt((p * (1 - p) + (z * z) / (4 * n)) / n)
-    return max(0.0, center - margin), min(1.0, center + margin)
-
-
+# ---- host bookkeeping around the matches: the score interval below, the Elo update, the model-pool files, the PBT
+# mutation and the checkpoint readers further down restate upstream's formulas, file formats and random-draw order
+# (train.py:596-781), because results and files must interchange with upstream's; nothing in them runs on the GPU.
 def _score_interval_from_counts(wins: int, losses: int, draws: int, z: float = 1.96):
     """Normal interval of the mean score with the empirical variance of outcomes {0, 0.5, 1} (train.py:596-610)."""
     total = wins + losses + draws
@@ -655,6 +672,24 @@ def _broadcast_flag(dist, value: bool, device) -> bool:
     return bool(int(t.item()))
 
 
+def sync_batchnorm_buffers(dist, model, world: int):
+    """Average the floating-point buffers (BatchNorm running_mean / running_var) over the ranks, and take rank 0's
+    integer ones (num_batches_tracked): each rank trained on its own batches, so these statistics differ while the
+    parameters do not. One flat all-reduce."""
+    floats = [b for b in model.buffers() if b.is_floating_point()]
+    if floats:
+        flat = torch.cat([b.detach().reshape(-1).to(torch.float32) for b in floats])
+        all_reduce_(dist, flat)
+        flat.div_(world)
+        off = 0
+        for b in floats:
+            b.copy_(flat[off:off + b.numel()].view_as(b))
+            off += b.numel()
+    for b in model.buffers():
+        if not b.is_floating_point():
+            broadcast_(dist, b, src=0)
+
+
 def run_training(cfg):
     """train.py:784-1023. Files written under cfg.save_dir have upstream's names and dict keys:
     iter_XXX.pt, best.pt, model_pool.json, model_pool/model_iter_XXX.pt, _runtime_best_vNNNNNN.pt."""
@@ -707,6 +742,8 @@ def run_training(cfg):
         candidate = build_model(cfg).to(dev)
         candidate.load_state_dict(copy.deepcopy(best_model.state_dict()))
         loss_mean, pol_mean, val_mean = train_candidate(candidate, buffer, cfg)
+        if dist is not None:   # parameters are equal on every rank (averaged gradients); BatchNorm running statistics are
+            sync_batchnorm_buffers(dist, candidate, world)   # not: average them, so every rank holds the network that is tested and saved
 
         promoted, arena = True, (0, 0, 0)
         if cfg.arena_games > 0 and rank == 0:

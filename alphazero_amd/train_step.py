@@ -66,6 +66,9 @@ class DataParallelTrainer:
         self.dist = dist if (dist.is_available() and dist.is_initialized()) else None
         self.group = process_group
         self.world = self.dist.get_world_size(process_group) if self.dist else 1
+        # under an initialised process group the gradients always go through the flat buffer and the collective, also with
+        # one rank (an identity there): a one-GPU run then executes the code path the N-GPU run takes
+        self.reduce = self.dist is not None
         self._flat = None
         if self.dist:  # identical starting weights on every rank
             for p in model.state_dict().values():
@@ -91,7 +94,7 @@ class DataParallelTrainer:
         self.model.train()
         if self.smooth > 0.0:
             target_policies = target_policies * (1.0 - self.smooth) + (self.smooth / target_policies.shape[1])
-        if self.dist and self.world > 1:
+        if self.reduce:
             if self._flat is None:
                 self._bind_flat_grads()
             else:
@@ -102,7 +105,7 @@ class DataParallelTrainer:
             logits, values = self.model(states)
             loss, pl, vl = loss_terms(logits, values, target_policies, target_values, self.delta, self.ent)
         self.scaler.scale(loss).backward()
-        if self.dist and self.world > 1:   # before unscale_: every rank then sees the same overflow verdict and the same scale
+        if self.reduce:   # before unscale_: every rank then sees the same overflow verdict and the same scale
             self._allreduce_grads()
         self.scaler.unscale_(self.opt)
         torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.clip)

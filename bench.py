@@ -2,20 +2,28 @@
 """Headline benchmark: lockstep self-play on MI355X, 9x9, 192ch x 12 SE blocks, 256 sims/move,
 top-k 48, virtual loss 1.0, 4096 games per GPU, random-init weights (synthetic).
 
-  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1: unless it already runs under torch.distributed.run (RANK in the environment), the script starts
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same flags>` as a child process
+before it touches the GPU and relays rank 0's line; one rank per GPU, RCCL ("nccl") for the barriers and the
+counter sums, no collective on the data path.
 
 A step is one lockstep move of every game on the rank: G x 256 simulations through rules, search and
 network. Rank 0 prints ONE JSON line. `value` = simulations of all ranks / max-over-ranks wall time.
-The roofline entry is for the dominant kernel (the fused bf16 MFMA tower), timed with HIP events on
-its launch stream inside the timed region. The cpu_baseline entry times the CPU oracle (C rules +
-search, PyTorch-CPU network, one process per core with one torch thread each, like the upstream
-multi-worker self-play) on a bounded sample of the same workload, rank 0 at N=1 only.
+`roofline` is for the dominant kernel (the fused bf16 MFMA tower), timed with HIP events on its launch
+stream inside the timed region; `roofline_other` gives the HBM-side figures of the search / rules kernels
+from an un-overlapped pass after the timed region. `cpu_baseline` times the CPU oracle (C rules + search,
+PyTorch-CPU network, one process per core with one torch thread each, like the upstream multi-worker
+self-play) on a bounded sample of the same workload, rank 0 at N=1 only.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,6 +33,7 @@ if ROOT not in sys.path:
 
 SIMS, TOPK, VLOSS, CH, BLOCKS = 256, 48, 1.0, 192, 12
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak of MI355X
+PEAK_HBM_TBPS = 8.0         # HBM3E peak
 
 
 def tower_flops_per_position(n=9, cin=21, ch=CH, blocks=BLOCKS):
@@ -41,18 +50,22 @@ def tower_flops_per_position(n=9, cin=21, ch=CH, blocks=BLOCKS):
 def tower_traffic_per_launch(rows_per_launch):
     """HBM-side bytes per tower launch from the committed PMC summary (separate FETCH_SIZE / WRITE_SIZE passes of
     this benchmark, collected offline: counters cannot be read from inside the run), scaled by rows."""
-    path = os.path.join(ROOT, "profiles", "r01h_tower_hbm_traffic.json")
-    try:
-        with open(path) as f:
-            d = json.load(f)
-        return round(d["bytes_per_launch"] / d.get("rows_per_launch", 1364.3) * rows_per_launch)
-    except (OSError, KeyError, ValueError):
-        return None
+    for name in ("r02_tower_hbm_traffic.json", "r01h_tower_hbm_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                d = json.load(f)
+            return round(d["bytes_per_launch"] / d.get("rows_per_launch", 1364.3) * rows_per_launch), name
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
 
 
+# ------------------------------------------------------------------------------------------------ CPU leg
 def cpu_worker(args):
-    """One CPU self-play worker: oracle search + torch CPU network, 1 thread (train.py:357-392 topology)."""
-    wid, moves, batch, seed = args
+    """One CPU self-play worker: oracle search + torch CPU network, 1 thread (train.py:357-392 topology).
+    dedup: rows of a batch with identical feature planes (the same leaf reached by several descents) are
+    evaluated once, the policy the GPU headline uses; otherwise every leaf is evaluated, as upstream does."""
+    wid, budget_s, batch, seed, dedup, plies = args
     import numpy as np
     import torch
     torch.set_num_threads(1)
@@ -61,42 +74,149 @@ def cpu_worker(args):
     from alphazero_amd.model import AlphaZeroNet
     torch.manual_seed(0)
     net = AlphaZeroNet(channels=CH, num_blocks=BLOCKS).eval()
+    rows_eval = [0]
 
     def ev(x):
+        if dedup and x.shape[0] > 1:
+            flat = x.reshape(x.shape[0], -1)
+            _, first, inv = np.unique(flat, axis=0, return_index=True, return_inverse=True)
+            with torch.inference_mode():
+                lg, v = net(torch.from_numpy(x[first]))
+            rows_eval[0] += len(first)
+            return lg.numpy()[inv.reshape(-1)], v.numpy()[inv.reshape(-1)]
         with torch.inference_mode():
             lg, v = net(torch.from_numpy(x))
+        rows_eval[0] += x.shape[0]
         return lg.numpy(), v.numpy()
 
     rng = np.random.RandomState(seed + wid)
     st = oracle.OracleState.new_game(9, 5.5, 8)
+    for _ in range(plies):                # a mid-game root: uniformly random legal stones
+        stones = np.nonzero(st.legal_mask()[:-1])[0]
+        if len(stones) == 0 or st.is_terminal():
+            break
+        st = st.play(int(rng.choice(stones)))
     m = oracle.OracleMCTS(ev, board_size=9, num_simulations=SIMS, inference_batch_size=batch, topk_expand=TOPK,
                           virtual_loss=VLOSS)
     ev(st.to_tensor()[None])          # warm up
+    rows_eval[0] = 0
     t0 = time.perf_counter()
-    sims = 0
-    for _ in range(moves):
+    sims = moves = 0
+    while time.perf_counter() - t0 < budget_s and not st.is_terminal():
         pi, a, _ = m.run(st, temperature=1.0, add_exploration_noise=True, rng=rng)
         st = st.play(a)
         sims += SIMS
-    return sims, time.perf_counter() - t0, m.stats()["rows"]
+        moves += 1
+    return sims, time.perf_counter() - t0, rows_eval[0], moves
 
 
-def cpu_baseline(batch, moves=2):
+def cpu_baseline(batch, budget_s=10.0):
     import multiprocessing as mp
     from oracle import oracle
     oracle.build()
-    cores = min(16, os.cpu_count() or 1)
+    visible = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    share = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)      # the GPU box exports its per-GPU CPU share here
+    cores = max(1, min(visible, share) if share > 0 else min(visible, 16))
     ctx = mp.get_context("spawn")
-    t0 = time.perf_counter()
+    legs = {}
     with ctx.Pool(cores) as pool:
-        res = pool.map(cpu_worker, [(w, moves, batch, 1234) for w in range(cores)])
-    wall = time.perf_counter() - t0
-    sims = sum(r[0] for r in res)
-    busy = max(r[1] for r in res)
-    return {"value": round(sims / busy, 1), "unit": "sims/s", "cores": cores, "kind": "port",
-            "sample": f"{cores} workers x {moves} moves x {SIMS} sims (inference batch {batch}, every leaf evaluated, "
-                      f"{sum(r[2] for r in res)} network rows), opening position, torch CPU 1 thread/worker; "
-                      f"{busy:.1f}s search time, {wall:.1f}s incl. worker start-up"}
+        for name, dedup in (("every_leaf", False), ("dedup", True)):
+            res = pool.map(cpu_worker, [(w, budget_s, batch, 1234, dedup, (w * 7) % 64) for w in range(cores)])
+            sims, busy, rows, moves = sum(r[0] for r in res), max(r[1] for r in res), sum(r[2] for r in res), sum(r[3] for r in res)
+            legs[name] = {"sims_per_s": round(sims / busy, 1), "nn_rows": rows, "moves": moves, "seconds": round(busy, 1)}
+    return {"value": legs["every_leaf"]["sims_per_s"], "unit": "sims/s", "cores": cores, "kind": "port",
+            "value_dedup_policy": legs["dedup"]["sims_per_s"],
+            "host_cpus_visible": visible,
+            "sample": f"{cores} workers (one process per core, 1 torch thread each) x {budget_s:.0f} s of whole moves x {SIMS} sims, inference batch "
+                      f"{batch}, roots after 0..63 random plies; leg 1 evaluates every leaf as upstream does "
+                      f"({legs['every_leaf']['moves']} moves, {legs['every_leaf']['nn_rows']} network rows) -> value; leg 2 evaluates a leaf "
+                      f"reached by several descents of a batch once, the GPU headline's policy ({legs['dedup']['moves']} moves, "
+                      f"{legs['dedup']['nn_rows']} rows) -> value_dedup_policy; cores = min(CPUs this process may use, the box's per-GPU CPU share)",
+            "reference_python_measured_in_build_container": "59.7 sims/s per 1-thread worker (BASELINE.md section 2; the upstream Python cannot run on the GPU box)"}
+
+
+# ------------------------------------------------------------------------------------------------ GPU side legs
+def mean_plies_per_game(net, cfg, games=256, seed0=900001):
+    """Whole games of the same network and search settings on a small lockstep batch: plies per finished game."""
+    from alphazero_amd.selfplay import BatchedSelfPlay
+    sp = BatchedSelfPlay(net, cfg, games=games, seed0=seed0, lanes=1, collect_samples=False)
+    sp.begin(num_games=games)
+    while sp.busy():
+        sp.step()
+    sp.flush()
+    return sp.counters["moves"] / max(1, sp.counters["games"]), sp.counters["games"]
+
+
+def kernel_census(net, batch, games, plies=24):
+    """Un-overlapped timing (events on the launch stream) of the search / rules kernels of one batch round on `games`
+    mid-game positions: k_select (+ row scan), k_leaf, k_expand_backup, against their algorithmic HBM bytes."""
+    import numpy as np
+    import torch
+    from alphazero_amd import _native as N
+    from alphazero_amd.engine import Engine
+    eng = Engine(board_size=9, games=games, num_simulations=SIMS, inference_batch_size=batch, topk_expand=TOPK, virtual_loss=VLOSS)
+    rng = np.random.default_rng(7)
+    for _ in range(plies):
+        lm = eng.legal_mask().cpu().numpy()[:, :-1].astype(np.float64)
+        lm[lm.sum(1) == 0] = 1.0
+        cdf = np.cumsum(lm / lm.sum(1, keepdims=True), axis=1)
+        acts = (cdf < rng.random((games, 1))).sum(1).astype(np.int32)
+        eng.play(torch.from_numpy(np.minimum(acts, 80)), raise_on_illegal=False)
+    nn = net.native("bf16", shared=False)
+    nn.reserve(eng.max_rows)
+    eng.search_begin()
+    rows = eng.pending()
+    feats = eng.gather(rows, N.AZ_FEAT_BF16_NHWC)
+    lg, v = nn(feats)
+    done = eng.expand(lg, v)
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    t_sel = t_leaf = t_exp = 0.0
+    n_rounds = leaves = 0
+    while not done:
+        e = [ev() for _ in range(5)]
+        e[0].record(); eng.search_select(); e[1].record()
+        rows = eng.pending()
+        e[2].record(); feats = eng.gather(rows, N.AZ_FEAT_BF16_NHWC); e[3].record()
+        lg, v = nn(feats)
+        e[3].synchronize()
+        t0 = ev(); t1 = ev()
+        t0.record(); done = eng.expand(lg, v); t1.record(); t1.synchronize()
+        t_sel += e[0].elapsed_time(e[1]); t_leaf += e[2].elapsed_time(e[3]); t_exp += t0.elapsed_time(t1)
+        n_rounds += 1
+        leaves += rows
+    st = eng.stats()
+    eng.close()
+    sims = st["sims"]
+    depth = st["depth_sum"] / max(1, sims)
+    kids = TOPK
+    b_select = sims * (depth * (kids * 26 + 12))                                  # children records read per level + path write
+    b_leaf = leaves * (81 + 8 * 81 + 8 * (plies + 1 + depth) + 81 * 32 * 2 + 82)  # board + history + seen keys in, planes + mask out
+    b_expand = leaves * (82 * 4 + 82 + kids * 26) + sims * (depth + 1) * 2 * 12   # logits + mask in, child records out; path read-modify-write
+    out = []
+    for name, ms, by, unit in (("k_select (+ k_scan_rows)", t_sel, b_select, f"{sims // n_rounds} sims/launch"),
+                               ("k_leaf", t_leaf, b_leaf, f"{leaves // n_rounds} leaves/launch"),
+                               ("k_expand_backup", t_exp, b_expand, f"{leaves // n_rounds} leaves + {sims // n_rounds} backups/launch")):
+        tb = by / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        out.append({"kernel": name, "bound": "hbm", "avg_launch_us": round(ms / n_rounds * 1e3, 1), "algorithmic_bytes_per_launch": int(by / n_rounds),
+                    "achieved_TBps": round(tb, 4), "peak_TBps": PEAK_HBM_TBPS, "frac": round(tb / PEAK_HBM_TBPS, 4), "units": unit})
+    return out, {"games": games, "root_plies": plies, "mean_leaf_depth": round(depth, 3), "rounds": n_rounds}
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n, argv):
+    """Start one rank per GPU as fresh child processes (this process has not touched the GPU) and relay their output."""
+    import torch
+    have = torch.cuda.device_count()          # counting devices does not initialise the GPU
+    if have < n:
+        raise SystemExit(f"bench.py --gpus {n}: this host shows {have} GPU(s); refusing to report a {n}-GPU figure from fewer ranks")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__), *argv]
+    return subprocess.call(cmd)
 
 
 def main():
@@ -110,55 +230,71 @@ def main():
     ap.add_argument("--lanes", type=int, default=3, help="independent game lanes (engine + stream each) whose kernels and host work overlap")
     ap.add_argument("--tower-workgroups", type=int, default=0, help="workgroup limit per tower launch (0: one per CU with 1 lane, 1024 otherwise)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-moves", type=int, default=8)
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="search time per CPU-baseline leg")
+    ap.add_argument("--no-side-legs", action="store_true", help="skip the no-dedup window, the kernel census and the plies-per-game run")
+    ap.add_argument("--force-dist", action="store_true", help="N=1: still go through a one-rank RCCL process group")
     a = ap.parse_args()
 
+    in_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if a.gpus > 1 and not in_launcher:
+        sys.exit(launch_ranks(a.gpus, sys.argv[1:]))
+
     import torch
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1")) if in_launcher else 1
+    rank = int(os.environ.get("RANK", "0")) if in_launcher else 0
+    local = int(os.environ.get("LOCAL_RANK", "0")) if in_launcher else 0
+    if world != a.gpus:
+        raise SystemExit(f"bench.py --gpus {a.gpus} was started with WORLD_SIZE={world}: the two must agree")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
+    if local >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: no GPU {local} on this host ({torch.cuda.device_count()} visible)")
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    if world > 1 or a.force_dist:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if not in_launcher:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        world = dist.get_world_size()
 
     from alphazero_amd.model import AlphaZeroNet
     from alphazero_amd.selfplay import BatchedSelfPlay, SelfPlayConfig
 
     torch.manual_seed(0)
-    net = AlphaZeroNet(channels=CH, num_blocks=BLOCKS).eval().to(torch.device("cuda", local))
+    dev = torch.device("cuda", local)
+    net = AlphaZeroNet(channels=CH, num_blocks=BLOCKS).eval().to(dev)
     cfg = SelfPlayConfig(mcts_simulations=SIMS, mcts_inference_batch=a.batch, mcts_topk_expand=TOPK, mcts_virtual_loss=VLOSS)
     twg = a.tower_workgroups if a.tower_workgroups > 0 else (None if a.lanes == 1 else 1024)
-    sp = BatchedSelfPlay(net, cfg, games=a.games, seed0=1 + rank * a.games, dedup_leaves=not a.no_dedup, lanes=a.lanes,
-                         tower_workgroups=twg)
-    sp.begin(num_games=10 ** 9)          # slots refill for as long as the run lasts
-    for _ in range(2):                   # set-up, before the W warm-up steps: first-use allocations (head-activation scratch
-        sp.step()                        # for the largest batch, torch's allocator pools) and filling the lane pipeline
-    for _ in range(a.warmup):
-        sp.step()
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for k in sp.counters:
-        sp.counters[k] = 0
-    sp.profile(True)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        sp.step()
-    barrier()
-    dt = time.perf_counter() - t0
-    tower_ms_sum, launches, tower_ms = sp.profile(False, read=True)   # tower_ms: merged (overlap counted once)
+    def window(sp, steps, warmup, setup=2):
+        sp.begin(num_games=10 ** 9)          # slots refill for as long as the run lasts
+        for _ in range(setup + warmup):      # `setup` steps before the W warm-up steps: first-use allocations of torch's
+            sp.step()                        # allocator pools and filling the lane pipeline
+        for k in sp.counters:
+            sp.counters[k] = 0
+        sp.profile(True)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            sp.step()
+        barrier()
+        dt = time.perf_counter() - t0
+        return dt, sp.profile(False, read=True)
 
-    c = sp.counters
+    sp = BatchedSelfPlay(net, cfg, games=a.games, seed0=1 + rank * a.games, dedup_leaves=not a.no_dedup, lanes=a.lanes,
+                         tower_workgroups=twg)
+    dt, (tower_ms_sum, launches, tower_ms) = window(sp, a.steps, a.warmup)   # tower_ms: merged (overlap counted once)
+
+    c = dict(sp.counters)
     mine = torch.tensor([dt, c["sims"], c["nn_rows"], c["nn_rows_nodedup"], c["moves"], c["games"], c["depth_sum"]],
-                        dtype=torch.float64, device=torch.device("cuda", local))
+                        dtype=torch.float64, device=dev)
     if dist is not None:
         tmax = mine[:1].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -169,6 +305,7 @@ def main():
         dt_max, tot = dt, mine.cpu().tolist()
     if rank != 0:
         if dist is not None:
+            dist.barrier()
             dist.destroy_process_group()
         return
 
@@ -177,6 +314,7 @@ def main():
     per_launch_ms = tower_ms / max(1, launches)
     tower_rows = c["nn_rows"]      # this rank's rows: every network row of the window went through a timed tower launch
     achieved = (tower_rows * fl_pos) / (tower_ms * 1e-3) / 1e12 if tower_ms > 0 else 0.0
+    traffic, traffic_src = tower_traffic_per_launch(tower_rows / max(1, launches))
     out = {
         "metric": "MCTS sims/sec (node) + self-play games/hour, 9x9 192ch×12blk @256 sims, 1/2/4/8 GPU",
         "value": round(sims / dt_max, 1), "unit": "sims/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -185,20 +323,16 @@ def main():
         "config": {"workload": "9x9 full net 192ch x 12 SE blocks, 256 sims/move, top-k 48, virtual loss 1.0, "
                                f"{a.games} lockstep games per GPU (BASELINE.json configs[2])",
                    "games_per_gpu": a.games, "lanes": a.lanes, "inference_batch": a.batch, "dedup_repeated_leaves": not a.no_dedup, "root_evaluation_reuse": True,
-                   "parallelism": f"games sharded over {world} GPU(s), no data-path collective"},
+                   "parallelism": f"games sharded over {world} GPU(s), one process per GPU, no data-path collective"},
         "sims_per_s": round(sims / dt_max, 1),
         "nn_rows_per_s": round(rows / dt_max, 1),
         "nn_rows_per_s_if_every_leaf_evaluated": round(rows_raw / dt_max, 1),
         "moves_per_s": round(moves / dt_max, 1),
-        "games_per_hour_est": round(moves / dt_max * 3600 / 162, 1),
-        "games_per_hour_note": "moves/s x 3600 / 162 plies (the 9x9 move cap; random-init self-play runs to the cap or two passes)",
-        "games_finished_in_window": int(games),
-        "games_per_hour_measured": round(games / dt_max * 3600, 1),   # meaningful for windows of a few hundred steps (--steps 330)
         "mean_leaf_depth": round(depth_sum / max(1.0, sims), 3),
         "roofline": {"bound": "mfma", "kernel": "k_tower<192,2,4,96,2>", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS,
                      "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
-                     "traffic": tower_traffic_per_launch(tower_rows / max(1, launches)),
-                     "traffic_note": "bytes per launch on the L2's memory side (Infinity Cache hits included), PMC passes in profiles/r01h_tower_hbm_traffic.json; "
+                     "traffic": traffic,
+                     "traffic_note": f"bytes per launch on the L2's memory side (Infinity Cache hits included), PMC passes in profiles/{traffic_src}; "
                                      "mostly the bf16 residual stream parked per workgroup between the two convolutions of a block",
                      "launches": int(launches), "avg_launch_ms": round(per_launch_ms, 4),
                      "avg_launch_ms_start_to_end": round(tower_ms_sum / max(1, launches), 4),
@@ -212,11 +346,29 @@ def main():
                      "tower_share_of_wall": round(tower_ms * 1e-3 / dt, 4)},
         "host_seconds": {"rng": round(c["t_host_rng"], 4), "policy": round(c["t_host_policy"], 4), "samples": round(c["t_samples"], 4)},
     }
+    del sp
+    if not a.no_side_legs:
+        # games/hour: moves/s of the timed window over the plies a finished game takes, measured on whole games of the same
+        # network and search settings in this run (a 4096-slot window of a few steps finishes no game of its own)
+        plies, n_games = mean_plies_per_game(net, cfg)
+        out["mean_plies_per_game"] = round(plies, 2)
+        out["games_per_hour"] = round(moves / dt_max * 3600 / plies, 1)
+        out["games_per_hour_note"] = (f"moves/s of the timed window x 3600 / {plies:.1f} plies per game, the mean over {n_games} whole games played "
+                                      "in this run with the same network and search settings (256 lockstep slots, untimed)")
+        if not a.no_dedup:   # the like-for-like figure for upstream's every-leaf evaluation: a short window of its own
+            sp2 = BatchedSelfPlay(net, cfg, games=a.games, seed0=1 + rank * a.games, dedup_leaves=False, lanes=a.lanes, tower_workgroups=twg)
+            dt2, _ = window(sp2, 2, 1, setup=1)
+            out["value_no_dedup"] = round(sp2.counters["sims"] / dt2, 1)
+            out["value_no_dedup_note"] = (f"sims/s of this rank over 2 steps with every leaf evaluated ({sp2.counters['nn_rows']} network rows for "
+                                          f"{sp2.counters['sims']} simulations), as upstream does")
+            del sp2
+        out["roofline_other"], out["roofline_other_setup"] = kernel_census(net, a.batch, a.games)
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
     if world == 1 and not a.no_cpu_baseline:
         try:
-            out["cpu_baseline"] = cpu_baseline(a.batch, a.cpu_moves)
+            out["cpu_baseline"] = cpu_baseline(a.batch, a.cpu_seconds)
         except Exception as e:  # the GPU number stands even if the CPU leg cannot run
             out["cpu_baseline"] = {"value": None, "unit": "sims/s", "cores": 0, "kind": "port", "sample": f"failed: {e!r}"}
     print(json.dumps(out))

@@ -162,12 +162,30 @@ int az_net_load(az_net* net, const float* params_host, int64_t count);
 int az_net_forward(az_net* net, const void* feat_dev, int32_t rows, float* logits_dev, float* values_dev,
                    void* stream);
 
+/* Allocate the activation scratch for forwards of up to `rows` positions now, so that az_net_forward /
+ * az_net_forward_indirect calls of that size allocate nothing and never wait for the device (without it the scratch
+ * grows at the first larger call; a replaced buffer is kept until az_net_destroy because enqueued launches may
+ * still use it). Same role as the lazily built torch workspace behind model(x) in mcts.py:59-64. */
+int az_net_reserve(az_net* net, int32_t rows);
+
 /* *fused = 1 if the bf16 network runs as the single fused tower kernel (boards up to 9x9, up to 192 channels), 0 if
- * it runs layer by layer (larger boards, 256 channels) or in float32; az_net_forward_indirect needs the fused kind. */
+ * it runs layer by layer (larger boards, 256 channels) or in float32. */
 int az_net_is_fused(az_net* net, int32_t* fused);
-/* Same with the row count read on the device from *rows_dev (<= max_rows): no host round trip. */
+/* az_net_forward with the row count read on the device from *rows_dev (<= max_rows): no host round trip. bf16
+ * networks of either kind; a layer-by-layer network runs whole chunks over max_rows whose surplus workgroups exit. */
 int az_net_forward_indirect(az_net* net, const void* feat_dev, const int32_t* rows_dev, int32_t max_rows,
                             float* logits_dev, float* values_dev, void* stream);
+/* az_net_forward for callers that cannot allocate device memory (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc): no counterpart upstream. Fused bf16 networks only. The activation
+ * scratch is a 64 MiB device array inside the library (one copy per GPU, held until the process ends): residual
+ * stream for 256 workgroups, then the head activations, which bounds `rows` by az_net_static_max_rows (2 697 rows
+ * for 9x9 / 192 channels); more rows return AZ_ERR_CAPACITY. The call allocates and frees nothing and records no
+ * events. Every network and every call on a GPU shares that GPU's array: calls that overlap on one GPU (other
+ * streams or threads) race; calls on one stream are ordered and safe. Results equal az_net_forward's bit for bit. */
+int az_net_forward_static(az_net* net, const void* feat_dev, int32_t rows, float* logits_dev, float* values_dev,
+                          void* stream);
+int64_t az_net_static_max_rows(const az_net* net);
+
 /* Timing of the dominant kernel (the fused tower) with HIP events recorded on the launch stream.
  * If the three output pointers are non-NULL they receive the total milliseconds, launch count and
  * row count accumulated since profiling was last enabled (synchronises on the recorded events);

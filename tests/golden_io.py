@@ -13,6 +13,15 @@ def load(name: str):
     return np.load(os.path.join(GOLDEN, name + ".npz"))
 
 
+def load_network(name: str):
+    """The pack that holds golden network `name`: network.npz or network_large.npz."""
+    for pack in ("network", "network_large"):
+        z = load(pack)
+        if f"{name}/logits" in z.files:
+            return z
+    raise KeyError(name)
+
+
 def games(pack: str) -> dict[str, dict[str, np.ndarray]]:
     z = load(pack)
     out: dict[str, dict[str, np.ndarray]] = {}
@@ -22,7 +31,7 @@ def games(pack: str) -> dict[str, dict[str, np.ndarray]]:
     return out
 
 
-RULE_PACKS = ("rules_scripted", "rules_5x5", "rules_9x9", "rules_19x19")
+RULE_PACKS = ("rules_scripted", "rules_5x5", "rules_9x9", "rules_19x19", "rules_edge")
 
 
 def all_rule_games():

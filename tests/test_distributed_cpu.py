@@ -147,13 +147,42 @@ def _loop_worker(rank, world, port, save):
 
     T.run_selfplay = fake_selfplay
     T._arena_results = fake_arena
+    trained = []
+    real_train = T.train_candidate
+
+    def spy_train(candidate, buffer, cfg):
+        trained.append(candidate)
+        return real_train(candidate, buffer, cfg)
+
+    T.train_candidate = spy_train
     cfg = T.parse_args(["--device", "cpu", "--board-size", "5", "--channels", "32", "--num-blocks", "1", "--value-hidden-dim", "32",
                         "--iterations", "3", "--selfplay-games-per-iter", "9", "--batch-size", "8", "--train-steps-per-iter", "2",
                         "--arena-games", "4", "--elo-games-per-opponent", "2", "--benchmark-games-per-opponent", "2",
                         "--save-dir", save, "--seed", "5"])
     T.run_training(cfg)
+    # each rank trained on its own batches: the BatchNorm running statistics must have been brought together, otherwise
+    # the ranks go on with different eval-mode networks from the first promotion on
+    flat = torch.cat([b.detach().reshape(-1).float() for b in trained[-1].buffers()])
+    both = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(both, flat)
+    assert torch.equal(both[0], both[1]), "BatchNorm buffers differ between the ranks"
+    assert float(flat.abs().sum()) > 0
     dist.barrier()
     dist.destroy_process_group()
+
+
+def test_selfplay_seed_ranges_do_not_overlap():
+    """Game j of iteration i is seeded seed + i*stride + j: upstream's stride of 1000 while an iteration has at most 1000
+    games, the game count beyond that, so that consecutive iterations never share a seed."""
+    sys.path.insert(0, ROOT)
+    from alphazero_amd import train as T
+    for games in (3, 1000, 1001, 4096):
+        cfg = T.parse_args(["--selfplay-games-per-iter", str(games), "--seed", "9"])
+        a = set(range(T.selfplay_seed0(cfg, 4), T.selfplay_seed0(cfg, 4) + games))
+        b = set(range(T.selfplay_seed0(cfg, 5), T.selfplay_seed0(cfg, 5) + games))
+        assert not (a & b)
+        if games <= 1000:
+            assert T.selfplay_seed0(cfg, 4) == 9 + 4 * 1000          # train.py:446
 
 
 def test_training_loop_collectives_line_up(tmp_path):

@@ -201,21 +201,30 @@ def test_pipelined_lanes_play_the_same_games(lanes):
 
 def test_lockstep_selfplay_on_19x19_layer_path():
     """19x19 (3 points per lane on the board kernels, network layer by layer): a few lockstep moves run, every
-    game's visit counts add up to the simulation count, and the search falls back to one round trip per batch."""
+    game's visit counts add up to the simulation count, and the batches of a search are enqueued without host round
+    trips (the layer kernels read the row count on the device); one round trip per batch plays the same moves."""
     import torch
     from alphazero_amd.model import AlphaZeroNet
     from alphazero_amd.selfplay import BatchedSelfPlay, SelfPlayConfig
     torch.manual_seed(5)
     net = AlphaZeroNet(board_size=19, channels=64, num_blocks=1).eval().cuda()
     cfg = SelfPlayConfig(board_size=19, mcts_simulations=12, mcts_inference_batch=4, mcts_topk_expand=16)
-    sp = BatchedSelfPlay(net, cfg, games=5, seed0=2)
-    assert not sp.async_search and not sp.net.fused
-    sp.begin(num_games=5)
-    for _ in range(3):
-        sp.step()
-    assert sp.counters["sims"] == 3 * 5 * 12 and sp.counters["moves"] == 15
-    for bits, caps, pi32, to_play, diff in sp.log:
-        assert pi32.shape == (5, 362) and np.allclose(pi32.sum(axis=1), 1.0, atol=1e-5)
+    logs = []
+    for use_async in (True, False):
+        sp = BatchedSelfPlay(net, cfg, games=5, seed0=2)
+        assert sp.async_search and not sp.net.fused
+        sp.set_async(use_async)
+        assert sp.async_search == use_async
+        sp.begin(num_games=5)
+        for _ in range(3):
+            sp.step()
+        assert sp.counters["sims"] == 3 * 5 * 12 and sp.counters["moves"] == 15
+        for bits, caps, pi32, to_play, diff in sp.log:
+            assert pi32.shape == (5, 362) and np.allclose(pi32.sum(axis=1), 1.0, atol=1e-5)
+        logs.append((list(sp.log), dict(sp.counters)))
+    for (ba, ca, pa, ta, da), (bb, cb, pb, tb, db) in zip(logs[0][0], logs[1][0]):
+        assert np.array_equal(ba, bb) and np.array_equal(pa, pb) and np.array_equal(ta, tb)
+    assert logs[0][1]["nn_rows"] == logs[1][1]["nn_rows"]
 
 
 def test_bench_line_contract():
@@ -225,7 +234,7 @@ def test_bench_line_contract():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--games", "192", "--lanes", "2",
-                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=root)
+                          "--no-cpu-baseline", "--no-side-legs"], capture_output=True, text=True, timeout=600, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1
@@ -334,3 +343,22 @@ def test_run_search_enqueued_without_round_trips_equals_stepwise():
         assert torch.equal(v0, v1) and torch.equal(r0, r1)
         assert int(v1.sum()) == 72 * (5 if enable is None else int(enable.sum()))
     eng.close()
+
+
+def test_bench_side_legs():
+    """The legs bench.py runs after the timed window (small game count): plies per finished game -> games/hour, the
+    every-leaf window, and the HBM-side census of the search / rules kernels."""
+    import json as _json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0", "--games", "192", "--lanes", "2",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = _json.loads([ln for ln in out.stdout.splitlines() if ln.strip()][-1])
+    assert 20 < d["mean_plies_per_game"] <= 162 and d["games_per_hour"] == pytest.approx(d["moves_per_s"] * 3600 / d["mean_plies_per_game"], rel=1e-2)
+    assert 0 < d["value_no_dedup"] < d["value"]
+    ks = d["roofline_other"]
+    assert [k["kernel"].split()[0] for k in ks] == ["k_select", "k_leaf", "k_expand_backup"]
+    for k in ks:
+        assert k["bound"] == "hbm" and k["avg_launch_us"] > 0 and abs(k["frac"] - k["achieved_TBps"] / k["peak_TBps"]) < 1e-3

@@ -20,7 +20,7 @@ def _to_nhwc_bf16(x, cpad=32):
 
 @pytest.mark.parametrize("name", GOLDEN_NETS)
 def test_f32_path_vs_golden_and_torch(name):
-    z = golden_io.load("network")
+    z = golden_io.load_network(name)
     net, x, kw = build_golden_net(name)
     with torch.inference_mode():
         lg_t, v_t = net(torch.from_numpy(x))
@@ -51,33 +51,47 @@ def _default_init(kw, seed=0):
     return net.eval()
 
 
-@pytest.mark.parametrize("name", [n for n in GOLDEN_NETS if "n19" not in n])
+# 32 channels on 19x19 has no bf16 kernel (az_net_create refuses it, test_unsupported_bf16_shape_is_refused; the float32
+# kernels serve it), every other golden network runs: four on the fused tower, two layer by layer
+BF16_GOLDEN = [n for n in GOLDEN_NETS if n != "n19_c32_b2_h4"]
+# Kernel vs rounding-point-exact emulation (tests/bf16_emul.py): the two differ only in float32 accumulation order, which
+# flips the bf16 rounding of an activation here and there. Measured on MI355X: see the printed kernel-vs-emulation errors.
+K_PROB, K_VAL, K_LOGIT = 2e-3, 2e-3, 2e-3
+
+
+@pytest.mark.parametrize("name", BF16_GOLDEN)
 @pytest.mark.parametrize("weights", ["default_init", "golden"])
 def test_bf16_path(name, weights):
+    """The bf16 kernels against (1) a PyTorch emulation that rounds exactly where they round -- pins the kernels whatever
+    the weights -- and (2) the float32 module: within 1e-2 abs on probabilities and value wherever bf16 inference itself
+    (= the emulation) is, and never worse than the emulation plus the kernel tolerance of (1)."""
+    import bf16_emul
+    import stubnets
     net, x, kw = build_golden_net(name)
     if weights == "default_init":
         net = _default_init(kw)
-    rng = np.random.default_rng(1)
-    import stubnets
     c = 2 * kw.get("history_len", 8) + 5
-    x = stubnets.synthetic_planes(37, c, kw["board_size"], seed=5)          # 37 rows: ragged last workgroup
+    rows = 37 if kw["board_size"] <= 9 else 7                                 # 37 rows: ragged last workgroup
+    x = stubnets.synthetic_planes(rows, c, kw["board_size"], seed=5)
+    xt = torch.from_numpy(x)
     with torch.inference_mode():
-        lg_t, v_t = net(torch.from_numpy(x))
+        lg_t, v_t = net(xt)
     dev = torch.device("cuda:0")
     nn = net.to(dev).native("bf16")
     lg, v = nn(_to_nhwc_bf16(x).to(dev))
     lg, v = lg.cpu(), v.cpu()
-    e_prob = float((lg.softmax(1) - lg_t.softmax(1)).abs().max())
-    e_val = float((v - v_t).abs().max())
-    e_lg = float((lg - lg_t).abs().max())
-    scale = float(lg_t.abs().max())
-    print(f"{name}/{weights}: bf16 prob err {e_prob:.3g}, value err {e_val:.3g}, logit err {e_lg:.3g} (logit scale {scale:.3g})")
-    # bf16 carries 8 significant bits: the absolute bound of 1e-2 holds while |logit| <= 1 and scales
-    # with the logit magnitude beyond that (the seed-generated "golden" weights reach |logit| ~ 37)
+    net = net.cpu()
+    lg_e, v_e = bf16_emul.emulate(net, xt, path="fused" if nn.fused else "layers")
+    scale = max(1.0, float(lg_t.abs().max()))
+    k_prob, k_val, k_lg = bf16_emul.errors(lg, v, lg_e, v_e)                  # kernel vs emulation
+    b_prob, b_val, b_lg = bf16_emul.errors(lg_e, v_e, lg_t, v_t)              # bf16 itself: emulation vs float32
+    e_prob, e_val, e_lg = bf16_emul.errors(lg, v, lg_t, v_t)                  # kernel vs float32
+    print(f"{name}/{weights} (|logit| {scale:.3g}): kernel-vs-emulation prob {k_prob:.3g} value {k_val:.3g} logit {k_lg:.3g} | "
+          f"bf16 itself prob {b_prob:.3g} value {b_val:.3g} logit {b_lg:.3g} | kernel-vs-f32 prob {e_prob:.3g} value {e_val:.3g} logit {e_lg:.3g}")
+    assert k_prob <= K_PROB and k_val <= K_VAL and k_lg <= K_LOGIT * scale
+    assert e_prob <= max(1e-2, b_prob + K_PROB) and e_val <= max(1e-2, b_val + K_VAL)
     if weights == "default_init":
-        assert e_val <= 1e-2 and e_lg <= 1e-2 and e_prob <= 1e-2
-    else:
-        assert e_lg <= 2e-2 * max(1.0, scale) and e_val <= 3e-2 and e_prob <= 1e-2 * max(1.0, scale / 4)
+        assert e_prob <= 1e-2 and e_val <= 1e-2 and e_lg <= 1e-2
 
 
 def test_bf16_rows_are_batch_invariant():
@@ -135,6 +149,49 @@ def test_bf16_layer_path(kw):
     assert torch.equal(lg[perm], lg_p) and torch.equal(v[perm], v_p)
     lg_1, v_1 = nn(f[4:5].contiguous())
     assert torch.equal(lg[4:5], lg_1) and torch.equal(v[4:5], v_1)
+
+
+def test_layer_path_forward_indirect_equals_direct():
+    """az_net_forward_indirect on the layer-by-layer path: the row count is read on the device, whole chunks are
+    launched over the upper bound and surplus workgroups leave; the live rows equal az_net_forward's bit for bit and
+    rows past the count are left untouched."""
+    from alphazero_amd.model import AlphaZeroNet
+    import stubnets
+    torch.manual_seed(12)
+    net = AlphaZeroNet(board_size=13, channels=64, num_blocks=2).eval()
+    x = stubnets.synthetic_planes(40, 21, 13, seed=8)
+    dev = torch.device("cuda:0")
+    nn = net.to(dev).native("bf16", shared=False)
+    assert not nn.fused and nn.indirect
+    f = _to_nhwc_bf16(x).to(dev)
+    lg, v = nn(f[:23].contiguous())
+    for live in (23, 1, 40):
+        rows_dev = torch.tensor([live], dtype=torch.int32, device=dev)
+        lb = torch.full((40, 170), -7.0, dtype=torch.float32, device=dev)
+        vb = torch.full((40,), -7.0, dtype=torch.float32, device=dev)
+        nn.forward_indirect(f, rows_dev.data_ptr(), 40, lb, vb)
+        k = min(live, 23)
+        assert torch.equal(lb[:k], lg[:k]) and torch.equal(vb[:k], v[:k])
+        assert bool((lb[live:] == -7.0).all()) and bool((vb[live:] == -7.0).all())
+
+
+def test_reserve_then_forward():
+    """az_net_reserve(rows) sizes the activation scratch ahead of time; forwards up to that size then use it as it is
+    (the entry point that can prove it allocates nothing is az_net_forward_static)."""
+    from alphazero_amd.model import AlphaZeroNet
+    import stubnets
+    torch.manual_seed(2)
+    dev = torch.device("cuda:0")
+    net = AlphaZeroNet(board_size=9, channels=64, num_blocks=1).eval().to(dev)
+    nn = net.native("bf16", shared=False)
+    nn.reserve(300)
+    f = _to_nhwc_bf16(stubnets.synthetic_planes(300, 21, 9, seed=1)).to(dev)
+    lg0, v0 = nn(f[:8].contiguous())
+    lg2, v2 = nn(f)
+    assert torch.equal(lg2[:8], lg0) and torch.equal(v2[:8], v0)
+    from alphazero_amd import _native as N
+    with pytest.raises(N.NativeError):
+        nn.reserve(0)
 
 
 FUSED = [dict(board_size=9, channels=128, num_blocks=2), dict(board_size=7, channels=128, num_blocks=1, history_len=4, use_se=False),

@@ -187,3 +187,77 @@ def test_two_rank_training_loop(tmp_path):
     assert "[Iter 2] selfplay B/W/D=" in outs[0][0] and "[Iter 2]" not in outs[1][0]
     tally = outs[0][0].split("[Iter 2] selfplay B/W/D=")[1].split()[0]
     assert sum(int(x) for x in tally.split("/")) == 10          # both ranks' games are counted
+
+
+_NCCL_ONE_RANK = r"""
+import os, sys, json, faulthandler
+faulthandler.dump_traceback_later(100, exit=True)
+sys.path.insert(0, os.environ["AZ_ROOT"]); sys.path.insert(0, os.path.join(os.environ["AZ_ROOT"], "tests"))
+import numpy as np, torch, torch.distributed as dist
+from alphazero_amd.model import AlphaZeroNet
+from alphazero_amd.train_step import DataParallelTrainer, all_reduce_, broadcast_
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+
+def fresh():
+    torch.manual_seed(3)
+    return AlphaZeroNet(board_size=5, channels=32, num_blocks=1, value_hidden_dim=64).to(dev)
+
+rng = np.random.default_rng(0)
+x = torch.from_numpy((rng.random((16, 21, 5, 5)) < 0.3).astype(np.float32)).to(dev)
+pi = torch.softmax(torch.from_numpy(rng.standard_normal((16, 26)).astype(np.float32)), 1).to(dev)
+z = torch.from_numpy(rng.choice([-1.0, 1.0], 16).astype(np.float32)).to(dev)
+plain = DataParallelTrainer(fresh(), total_steps=4)              # no process group yet: plain autograd path
+want = [plain.step(x, pi, z) for _ in range(3)]
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+t = torch.arange(8, dtype=torch.float32, device=dev)
+all_reduce_(dist, t); broadcast_(dist, t); dist.barrier()
+assert torch.equal(t.cpu(), torch.arange(8, dtype=torch.float32))
+tr = DataParallelTrainer(fresh(), total_steps=4)                 # flat gradient buffer + RCCL all-reduce every step
+assert tr.reduce
+got = [tr.step(x, pi, z) for _ in range(3)]
+assert tr._flat is not None and tr._flat.numel() == sum(p.numel() for p in tr.model.parameters())
+same = all(torch.equal(a, b) for a, b in zip(plain.model.state_dict().values(), tr.model.state_dict().values()))
+dist.destroy_process_group()
+print("RESULT " + json.dumps({"want": want, "got": got, "same_weights": bool(same)}))
+"""
+
+
+def test_nccl_path_one_rank(tmp_path):
+    """The production backend on the hardware that is there: a one-rank RCCL process group carries the trainer's flat
+    gradient all-reduce, a broadcast and a barrier, and is torn down; the step equals the plain single-process step."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, AZ_ROOT=root, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    out = subprocess.run([sys.executable, "-u", "-c", _NCCL_ONE_RANK], env=env, capture_output=True, text=True, timeout=150)
+    assert out.returncode == 0, out.stderr[-3000:]
+    res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("RESULT ")][0][7:])
+    assert res["same_weights"]
+    assert np.allclose(np.array(res["want"]), np.array(res["got"]), rtol=0, atol=0)
+
+
+def test_bench_rank_launch(tmp_path):
+    """bench.py --gpus N starts N ranks itself. On this one-GPU box: --gpus 2 refuses loudly instead of printing a
+    one-rank figure, and --gpus 1 --force-dist goes through the RCCL branch (init, barriers, counter all-reduce,
+    destroy) with n_gpus read from the process group."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    bench = os.path.join(root, "bench.py")
+    if torch.cuda.device_count() < 2:
+        two = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "1", "--warmup", "0", "--games", "96", "--no-cpu-baseline"],
+                             capture_output=True, text=True, timeout=120, cwd=root)
+        assert two.returncode != 0 and "GPU" in two.stderr and not two.stdout.strip()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    one = subprocess.run([sys.executable, bench, "--gpus", "1", "--force-dist", "--steps", "1", "--warmup", "0", "--games", "96", "--lanes", "2",
+                          "--no-cpu-baseline", "--no-side-legs"], capture_output=True, text=True, timeout=300, cwd=root, env=env)
+    assert one.returncode == 0, one.stderr[-3000:]
+    d = json.loads([ln for ln in one.stdout.splitlines() if ln.strip()][-1])
+    assert d["n_gpus"] == 1 and d["value"] > 0
+    # under the launcher's environment the rank count must match --gpus
+    bad = subprocess.run([sys.executable, bench, "--gpus", "1", "--steps", "1", "--games", "96", "--no-cpu-baseline", "--no-side-legs"],
+                         capture_output=True, text=True, timeout=120, cwd=root,
+                         env=dict(env, RANK="0", WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port())))
+    assert bad.returncode != 0 and "must agree" in bad.stderr

@@ -18,7 +18,7 @@ def test_alias():
 
 @pytest.mark.parametrize("name", GOLDEN_NETS)
 def test_state_dict_contract_and_outputs(name):
-    z = golden_io.load("network")
+    z = golden_io.load_network(name)
     net, x, kw = build_golden_net(name)
     shapes = json.loads(bytes(z[f"{name}/shapes_json"]).decode())
     sd = net.state_dict()

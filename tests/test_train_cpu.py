@@ -116,8 +116,6 @@ def test_sample_filter():
 
 
 def test_arena_statistics_and_elo():
-    for s, n, lo, hi in J["wilson"]:
-        assert T._wilson_interval(s, n) == (lo, hi)
     for w, l, d, lo, hi in J["score_interval"]:
         assert T._score_interval_from_counts(w, l, d) == (lo, hi)
     for ra, rb, sc, g, k, ex, na, nb in J["elo"]:

@@ -7,7 +7,7 @@ import torch
 import golden_io
 import stubnets
 
-GOLDEN_NETS = ["n5_c32_b1", "n9_c64_b4", "n9_c64_b2_nose", "n9_c192_b12", "n19_c32_b2_h4"]
+GOLDEN_NETS = ["n5_c32_b1", "n9_c64_b4", "n9_c64_b2_nose", "n9_c192_b12", "n19_c32_b2_h4", "n19_c128_b3", "n13_c64_b2"]
 
 
 def hash_name(s: str) -> int:
@@ -20,7 +20,7 @@ def hash_name(s: str) -> int:
 def build_golden_net(name):
     """The net with the seed-generated weights used for tests/golden/network.npz, its input, its kwargs."""
     from alphazero_amd.model import AlphaZeroNet
-    z = golden_io.load("network")
+    z = golden_io.load_network(name)
     kw = json.loads(bytes(z[f"{name}/cfg_json"]).decode())
     net = AlphaZeroNet(**kw)
     shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
