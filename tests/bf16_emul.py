@@ -37,7 +37,7 @@ def _fold(conv_w, bn, eps=1e-5):
 
 @torch.no_grad()
 def emulate(net, x: torch.Tensor, weights: bool = True, activations: bool = True, residual: str = "bf16",
-            se_image: bool | None = None, path: str = "fused"):
+            se_image: bool | None = None, path: str = "fused", accumulate: str = "f32"):
     """(logits, value) of AlphaZeroNet `net` (eval mode) on float32 NCHW planes `x`.
 
     weights: round folded conv / SE / value-fc1 weights to bf16. activations: round the activations where the
@@ -46,7 +46,15 @@ def emulate(net, x: torch.Tensor, weights: bool = True, activations: bool = True
     path: "fused" = the single-kernel tower (boards up to 9x9, up to 192 channels); "layers" = the layer-by-layer
     kernels (larger boards, 256 channels), which differ in three places: y itself is stored as bf16 before the gate is
     applied, the squeeze-excite weights stay float32, and the skip connection is always the bf16 image.
+    accumulate: "f32", or "f64" = every convolution accumulates in float64 and is rounded to float32 once: the distance
+    between the two is how much these weights amplify a change of summation order alone (flipped bf16 roundings that
+    propagate), i.e. the scale below which two correct implementations cannot be told apart on them.
     """
+    def conv(a, w, b=None, **k):
+        if accumulate == "f64":
+            return F.conv2d(a.double(), w.double(), None if b is None else b.double(), **k).float()
+        return F.conv2d(a, w, b, **k)
+
     if se_image is None:
         se_image = activations
     layers = path == "layers"
@@ -54,30 +62,30 @@ def emulate(net, x: torch.Tensor, weights: bool = True, activations: bool = True
         residual = "bf16"
     x = _r(x.float(), activations)
     w, b = _fold(net.stem[0].weight, net.stem[1])
-    t = F.relu(F.conv2d(x, _r(w, weights), b, padding=1))
+    t = F.relu(conv(x, _r(w, weights), b, padding=1))
     skip = t if residual == "f32" else _r(t, activations)
     t = _r(t, activations)
     for blk in net.tower:
         w1, b1 = _fold(blk.conv1.weight, blk.bn1)
         w2, b2 = _fold(blk.conv2.weight, blk.bn2)
-        h = _r(F.relu(F.conv2d(t, _r(w1, weights), b1, padding=1)), activations)
-        y = F.conv2d(h, _r(w2, weights), b2, padding=1)
+        h = _r(F.relu(conv(t, _r(w1, weights), b1, padding=1)), activations)
+        y = conv(h, _r(w2, weights), b2, padding=1)
         if layers:
             y = _r(y, activations)
         if not isinstance(blk.se, torch.nn.Identity):
             fc1, fc2 = blk.se.net[1], blk.se.net[3]
             pooled = _r(y, se_image).mean(dim=(2, 3), keepdim=True)
-            hid = F.relu(F.conv2d(pooled, _r(fc1.weight, weights and not layers), fc1.bias))
-            y = y * torch.sigmoid(F.conv2d(hid, _r(fc2.weight, weights and not layers), fc2.bias))
+            hid = F.relu(conv(pooled, _r(fc1.weight, weights and not layers), fc1.bias))
+            y = y * torch.sigmoid(conv(hid, _r(fc2.weight, weights and not layers), fc2.bias))
         nxt = F.relu(y + skip)
         skip = nxt if residual == "f32" else _r(nxt, activations)
         t = _r(nxt, activations)
     wp, bp = _fold(net.policy_head[0].weight, net.policy_head[1])
     wv, bv = _fold(net.value_head[0].weight, net.value_head[1])
-    p = _r(F.relu(F.conv2d(t, _r(wp, weights), bp)), activations)
-    v = _r(F.relu(F.conv2d(t, _r(wv, weights), bv)), activations)
+    p = _r(F.relu(conv(t, _r(wp, weights), bp)), activations)
+    v = _r(F.relu(conv(t, _r(wv, weights), bv)), activations)
     w3, b3 = _fold(net.policy_head[3].weight, net.policy_head[4])
-    p = F.relu(F.conv2d(p, w3, b3)).flatten(1)
+    p = F.relu(conv(p, w3, b3)).flatten(1)
     logits = F.linear(p, net.policy_fc.weight, net.policy_fc.bias)
     fc4, fc6 = net.value_head[4], net.value_head[6]
     hv = F.relu(F.linear(v.flatten(1), _r(fc4.weight, weights), fc4.bias))

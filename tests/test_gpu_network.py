@@ -54,17 +54,7 @@ def _default_init(kw, seed=0):
 # 32 channels on 19x19 has no bf16 kernel (az_net_create refuses it, test_unsupported_bf16_shape_is_refused; the float32
 # kernels serve it), every other golden network runs: four on the fused tower, two layer by layer
 BF16_GOLDEN = [n for n in GOLDEN_NETS if n != "n19_c32_b2_h4"]
-# Kernel vs rounding-point-exact emulation (tests/bf16_emul.py): the two differ only in float32 accumulation order, which
-# flips the bf16 rounding of an activation here and there. Measured on MI355X: see the printed kernel-vs-emulation errors.
-K_PROB, K_VAL, K_LOGIT = 2e-3, 2e-3, 2e-3
-
-
-@pytest.mark.parametrize("name", BF16_GOLDEN)
-@pytest.mark.parametrize("weights", ["default_init", "golden"])
-def test_bf16_path(name, weights):
-    """The bf16 kernels against (1) a PyTorch emulation that rounds exactly where they round -- pins the kernels whatever
-    the weights -- and (2) the float32 module: within 1e-2 abs on probabilities and value wherever bf16 inference itself
-    (= the emulation) is, and never worse than the emulation plus the kernel tolerance of (1)."""
+def _bf16_case(name, weights):
     import bf16_emul
     import stubnets
     net, x, kw = build_golden_net(name)
@@ -81,17 +71,70 @@ def test_bf16_path(name, weights):
     lg, v = nn(_to_nhwc_bf16(x).to(dev))
     lg, v = lg.cpu(), v.cpu()
     net = net.cpu()
-    lg_e, v_e = bf16_emul.emulate(net, xt, path="fused" if nn.fused else "layers")
+    path = "fused" if nn.fused else "layers"
+    lg_e, v_e = bf16_emul.emulate(net, xt, path=path)
+    lg_6, v_6 = bf16_emul.emulate(net, xt, path=path, accumulate="f64")
     scale = max(1.0, float(lg_t.abs().max()))
-    k_prob, k_val, k_lg = bf16_emul.errors(lg, v, lg_e, v_e)                  # kernel vs emulation
-    b_prob, b_val, b_lg = bf16_emul.errors(lg_e, v_e, lg_t, v_t)              # bf16 itself: emulation vs float32
-    e_prob, e_val, e_lg = bf16_emul.errors(lg, v, lg_t, v_t)                  # kernel vs float32
-    print(f"{name}/{weights} (|logit| {scale:.3g}): kernel-vs-emulation prob {k_prob:.3g} value {k_val:.3g} logit {k_lg:.3g} | "
-          f"bf16 itself prob {b_prob:.3g} value {b_val:.3g} logit {b_lg:.3g} | kernel-vs-f32 prob {e_prob:.3g} value {e_val:.3g} logit {e_lg:.3g}")
-    assert k_prob <= K_PROB and k_val <= K_VAL and k_lg <= K_LOGIT * scale
-    assert e_prob <= max(1e-2, b_prob + K_PROB) and e_val <= max(1e-2, b_val + K_VAL)
-    if weights == "default_init":
-        assert e_prob <= 1e-2 and e_val <= 1e-2 and e_lg <= 1e-2
+    k = bf16_emul.errors(lg, v, lg_e, v_e)                  # kernel vs emulation
+    s = bf16_emul.errors(lg_e, v_e, lg_6, v_6)              # emulation vs itself with another summation order
+    b = bf16_emul.errors(lg_e, v_e, lg_t, v_t)              # bf16 itself: emulation vs the float32 module
+    e = bf16_emul.errors(lg, v, lg_t, v_t)                  # kernel vs the float32 module
+    print(f"{name}/{weights} (|logit| {scale:.3g}) prob/value/logit: kernel-vs-emulation {k[0]:.3g} {k[1]:.3g} {k[2]:.3g} | summation-order "
+          f"sensitivity of the emulation {s[0]:.3g} {s[1]:.3g} {s[2]:.3g} | bf16 itself {b[0]:.3g} {b[1]:.3g} {b[2]:.3g} | kernel-vs-f32 "
+          f"{e[0]:.3g} {e[1]:.3g} {e[2]:.3g}")
+    return k, s, b, e, scale
+
+
+@pytest.mark.parametrize("name", BF16_GOLDEN)
+def test_bf16_path_default_init(name):
+    """Well-conditioned weights (framework initialisers, non-trivial BatchNorm statistics): the bf16 kernels are within
+    1e-2 abs of the float32 module on logits, probabilities and value, and within a few 1e-3 of a PyTorch emulation that
+    rounds exactly where they round (the two differ in float32 summation order only)."""
+    k, s, b, e, scale = _bf16_case(name, "default_init")
+    assert e[0] <= 1e-2 and e[1] <= 1e-2 and e[2] <= 1e-2
+    assert k[0] <= 2e-4 and k[1] <= 2e-3 and k[2] <= 3e-3
+
+
+@pytest.mark.parametrize("name", BF16_GOLDEN)
+def test_bf16_path_golden_weights(name):
+    """The seed-generated golden weights are deliberately large (|logit| up to 37) and ill-conditioned in bf16: rounding the
+    weights alone moves probabilities by up to 0.028 (profiles/r02_bf16_error_budget.json), and a mere change of summation
+    order inside the emulation moves the outputs as much as the kernels differ from it. So the bounds are the emulation's:
+    kernel-vs-emulation within 4x the emulation's own summation-order sensitivity (+ a floor for the cases where that is
+    tiny), and kernel-vs-float32 no further out than bf16 inference itself (emulation-vs-float32) plus that allowance;
+    1e-2 abs wherever bf16 itself achieves it. Kernel correctness proper is pinned without any tolerance by
+    test_bf16_exact_integer_network."""
+    k, s, b, e, scale = _bf16_case(name, "golden_weights")
+    floor = (1e-3, 3e-3, 5e-3 * scale)
+    for i in range(3):
+        allow = 4.0 * s[i] + floor[i]
+        assert k[i] <= allow, (i, k[i], allow)
+        assert e[i] <= max(1e-2 if i < 2 else 0.0, b[i] + allow), (i, e[i], b[i], allow)
+
+
+EXACT = [("fused", dict(board_size=9, channels=192, num_blocks=12), 40), ("fused", dict(board_size=9, channels=128, num_blocks=3), 40),
+         ("fused", dict(board_size=9, channels=64, num_blocks=4, use_se=False), 41), ("fused", dict(board_size=5, channels=32, num_blocks=2, value_hidden_dim=64), 23),
+         ("fused", dict(board_size=7, channels=128, num_blocks=3, history_len=4), 17), ("fused", dict(board_size=6, channels=192, num_blocks=2), 15),
+         ("layers", dict(board_size=13, channels=64, num_blocks=2), 5), ("layers", dict(board_size=19, channels=128, num_blocks=2), 4),
+         ("layers", dict(board_size=19, channels=256, num_blocks=3), 3), ("layers", dict(board_size=9, channels=256, num_blocks=2, value_hidden_dim=64), 9)]
+
+
+@pytest.mark.parametrize("path,kw,rows", EXACT, ids=[f"{p}-n{k['board_size']}_c{k['channels']}_b{k['num_blocks']}" for p, k, _ in EXACT])
+def test_bf16_exact_integer_network(path, kw, rows):
+    """Networks with small-integer weights, binary inputs and squeeze-excite gates that saturate to exactly 0 or 1
+    (tests/exactnet.py): no value is ever rounded, so every correct implementation gives the same logits bit for bit,
+    whatever its tiling or summation order. The kernels must equal the emulation exactly on every row, including the
+    ragged last board group; the value (a tanh) to 2e-6."""
+    import exactnet
+    net, x, lg_want, v_want = exactnet.find_exact_net(kw, path, rows)
+    dev = torch.device("cuda:0")
+    nn = net.to(dev).native("bf16", shared=False)
+    assert nn.fused == (path == "fused")
+    lg, v = nn(_to_nhwc_bf16(x).to(dev))
+    lg, v = lg.cpu(), v.cpu()
+    bad = (lg != lg_want).nonzero()
+    assert bad.numel() == 0, f"{bad.shape[0]} logits differ, first at row/action {bad[0].tolist()}: {float(lg[tuple(bad[0])])} vs {float(lg_want[tuple(bad[0])])}"
+    assert float((v - v_want).abs().max()) <= 2e-6
 
 
 def test_bf16_rows_are_batch_invariant():

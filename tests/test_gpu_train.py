@@ -208,7 +208,9 @@ x = torch.from_numpy((rng.random((16, 21, 5, 5)) < 0.3).astype(np.float32)).to(d
 pi = torch.softmax(torch.from_numpy(rng.standard_normal((16, 26)).astype(np.float32)), 1).to(dev)
 z = torch.from_numpy(rng.choice([-1.0, 1.0], 16).astype(np.float32)).to(dev)
 plain = DataParallelTrainer(fresh(), total_steps=4)              # no process group yet: plain autograd path
-want = [plain.step(x, pi, z) for _ in range(3)]
+want = [plain.step(x, pi, z)]
+g_plain = torch.cat([p.grad.reshape(-1) for p in plain.model.parameters()]).clone()   # clipped gradient of step 1
+want += [plain.step(x, pi, z) for _ in range(2)]
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
 t = torch.arange(8, dtype=torch.float32, device=dev)
@@ -216,11 +218,13 @@ all_reduce_(dist, t); broadcast_(dist, t); dist.barrier()
 assert torch.equal(t.cpu(), torch.arange(8, dtype=torch.float32))
 tr = DataParallelTrainer(fresh(), total_steps=4)                 # flat gradient buffer + RCCL all-reduce every step
 assert tr.reduce
-got = [tr.step(x, pi, z) for _ in range(3)]
+got = [tr.step(x, pi, z)]
 assert tr._flat is not None and tr._flat.numel() == sum(p.numel() for p in tr.model.parameters())
-same = all(torch.equal(a, b) for a, b in zip(plain.model.state_dict().values(), tr.model.state_dict().values()))
+assert all(p.grad.data_ptr() >= tr._flat.data_ptr() for p in tr.model.parameters())      # gradients are views of the flat buffer
+g_err = float((tr._flat - g_plain).abs().max() / g_plain.abs().max())                   # convolution backward is not bitwise repeatable
+got += [tr.step(x, pi, z) for _ in range(2)]
 dist.destroy_process_group()
-print("RESULT " + json.dumps({"want": want, "got": got, "same_weights": bool(same)}))
+print("RESULT " + json.dumps({"want": want, "got": got, "grad_rel_err": g_err}))
 """
 
 
@@ -234,8 +238,8 @@ def test_nccl_path_one_rank(tmp_path):
     out = subprocess.run([sys.executable, "-u", "-c", _NCCL_ONE_RANK], env=env, capture_output=True, text=True, timeout=150)
     assert out.returncode == 0, out.stderr[-3000:]
     res = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("RESULT ")][0][7:])
-    assert res["same_weights"]
-    assert np.allclose(np.array(res["want"]), np.array(res["got"]), rtol=0, atol=0)
+    assert res["grad_rel_err"] < 1e-4
+    assert np.allclose(np.array(res["want"]), np.array(res["got"]), rtol=1e-3, atol=1e-4)
 
 
 def test_bench_rank_launch(tmp_path):
