@@ -31,7 +31,17 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-SIMS, TOPK, VLOSS, CH, BLOCKS = 256, 48, 1.0, 192, 12
+SIMS, TOPK, VLOSS, CH, BLOCKS = 256, 48, 1.0, 192, 12       # the headline workload (BASELINE.json configs[2])
+# --config N selects one of BASELINE.json's other GPU configurations (1-based, as the survey numbers them); they are
+# parity-test shapes whose lines are kept under profiles/, not the headline
+WORKLOADS = {
+    3: dict(board=9, ch=192, blocks=12, sims=256, topk=48, games=4096, lanes=3, batch=16,
+            text="9x9 full net 192ch x 12 SE blocks, 256 sims/move, top-k 48, virtual loss 1.0, {g} lockstep games per GPU (BASELINE.json configs[2])"),
+    2: dict(board=9, ch=64, blocks=4, sims=192, topk=0, games=512, lanes=2, batch=16,
+            text="9x9 small net 64ch x 4 blocks, 192 sims/move, {g} lockstep games per GPU (BASELINE.json configs[1])"),
+    5: dict(board=19, ch=256, blocks=20, sims=800, topk=48, games=512, lanes=2, batch=16,
+            text="19x19 256ch x 20 SE blocks, 800 sims/move, history 8, top-k 48, {g} lockstep games per GPU (per-GPU share of BASELINE.json configs[4])"),
+}
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak of MI355X
 PEAK_HBM_TBPS = 8.0         # HBM3E peak
 
@@ -224,16 +234,21 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--games", type=int, default=4096, help="lockstep games per GPU")
+    ap.add_argument("--config", type=int, default=3, choices=sorted(WORKLOADS), help="BASELINE.json configuration (3 = headline)")
+    ap.add_argument("--games", type=int, default=0, help="lockstep games per GPU (0: the configuration's)")
     ap.add_argument("--batch", type=int, default=16, help="mcts inference batch (README value 16; upstream default 8)")
     ap.add_argument("--no-dedup", action="store_true", help="evaluate repeated leaves of a batch again, as upstream does")
-    ap.add_argument("--lanes", type=int, default=3, help="independent game lanes (engine + stream each) whose kernels and host work overlap")
+    ap.add_argument("--lanes", type=int, default=0, help="independent game lanes (engine + stream each) whose kernels and host work overlap (0: the configuration's)")
     ap.add_argument("--tower-workgroups", type=int, default=0, help="workgroup limit per tower launch (0: one per CU with 1 lane, 1024 otherwise)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="search time per CPU-baseline leg")
     ap.add_argument("--no-side-legs", action="store_true", help="skip the no-dedup window, the kernel census and the plies-per-game run")
     ap.add_argument("--force-dist", action="store_true", help="N=1: still go through a one-rank RCCL process group")
     a = ap.parse_args()
+    wl = WORKLOADS[a.config]
+    a.games = a.games or wl["games"]
+    a.lanes = a.lanes or wl["lanes"]
+    headline = a.config == 3
 
     in_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
     if a.gpus > 1 and not in_launcher:
@@ -264,8 +279,9 @@ def main():
 
     torch.manual_seed(0)
     dev = torch.device("cuda", local)
-    net = AlphaZeroNet(channels=CH, num_blocks=BLOCKS).eval().to(dev)
-    cfg = SelfPlayConfig(mcts_simulations=SIMS, mcts_inference_batch=a.batch, mcts_topk_expand=TOPK, mcts_virtual_loss=VLOSS)
+    net = AlphaZeroNet(board_size=wl["board"], channels=wl["ch"], num_blocks=wl["blocks"]).eval().to(dev)
+    cfg = SelfPlayConfig(board_size=wl["board"], mcts_simulations=wl["sims"], mcts_inference_batch=a.batch, mcts_topk_expand=wl["topk"],
+                         mcts_virtual_loss=VLOSS)
     twg = a.tower_workgroups if a.tower_workgroups > 0 else (None if a.lanes == 1 else 1024)
 
     def barrier():
@@ -310,7 +326,8 @@ def main():
         return
 
     sims, rows, rows_raw, moves, games, depth_sum = tot[1:]
-    fl_pos = tower_flops_per_position()
+    fl_pos = tower_flops_per_position(wl["board"], 21, wl["ch"], wl["blocks"])
+    fused = wl["board"] <= 9 and wl["ch"] <= 192
     per_launch_ms = tower_ms / max(1, launches)
     tower_rows = c["nn_rows"]      # this rank's rows: every network row of the window went through a timed tower launch
     achieved = (tower_rows * fl_pos) / (tower_ms * 1e-3) / 1e12 if tower_ms > 0 else 0.0
@@ -320,8 +337,7 @@ def main():
         "value": round(sims / dt_max, 1), "unit": "sims/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(dt_max / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic (random-init weights, games from the empty board)",
-        "config": {"workload": "9x9 full net 192ch x 12 SE blocks, 256 sims/move, top-k 48, virtual loss 1.0, "
-                               f"{a.games} lockstep games per GPU (BASELINE.json configs[2])",
+        "config": {"workload": wl["text"].format(g=a.games),
                    "games_per_gpu": a.games, "lanes": a.lanes, "inference_batch": a.batch, "dedup_repeated_leaves": not a.no_dedup, "root_evaluation_reuse": True,
                    "parallelism": f"games sharded over {world} GPU(s), one process per GPU, no data-path collective"},
         "sims_per_s": round(sims / dt_max, 1),
@@ -329,9 +345,10 @@ def main():
         "nn_rows_per_s_if_every_leaf_evaluated": round(rows_raw / dt_max, 1),
         "moves_per_s": round(moves / dt_max, 1),
         "mean_leaf_depth": round(depth_sum / max(1.0, sims), 3),
-        "roofline": {"bound": "mfma", "kernel": "k_tower<192,2,4,96,2>", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS,
+        "roofline": {"bound": "mfma", "kernel": ("k_tower<192,2,4,96,2>" if headline else f"k_tower<{wl['ch']},...>") if fused else
+                     "layer-by-layer network (k_conv3_slab + gate / residual / tail kernels), timed as one sequence", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS,
                      "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
-                     "traffic": traffic,
+                     "traffic": traffic if headline else None,
                      "traffic_note": f"bytes per launch on the L2's memory side (Infinity Cache hits included), PMC passes in profiles/{traffic_src}; "
                                      "mostly the bf16 residual stream parked per workgroup between the two convolutions of a block",
                      "launches": int(launches), "avg_launch_ms": round(per_launch_ms, 4),
@@ -347,7 +364,7 @@ def main():
         "host_seconds": {"rng": round(c["t_host_rng"], 4), "policy": round(c["t_host_policy"], 4), "samples": round(c["t_samples"], 4)},
     }
     del sp
-    if not a.no_side_legs:
+    if not a.no_side_legs and headline:
         # games/hour: moves/s of the timed window over the plies a finished game takes, measured on whole games of the same
         # network and search settings in this run (a 4096-slot window of a few steps finishes no game of its own)
         plies, n_games = mean_plies_per_game(net, cfg)
@@ -366,7 +383,7 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    if world == 1 and not a.no_cpu_baseline:
+    if world == 1 and not a.no_cpu_baseline and headline:
         try:
             out["cpu_baseline"] = cpu_baseline(a.batch, a.cpu_seconds)
         except Exception as e:  # the GPU number stands even if the CPU leg cannot run

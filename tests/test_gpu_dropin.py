@@ -362,3 +362,43 @@ def test_bench_side_legs():
     assert [k["kernel"].split()[0] for k in ks] == ["k_select", "k_leaf", "k_expand_backup"]
     for k in ks:
         assert k["bound"] == "hbm" and k["avg_launch_us"] > 0 and abs(k["frac"] - k["achieved_TBps"] / k["peak_TBps"]) < 1e-3
+
+
+def test_config5_shape_lockstep_moves():
+    """BASELINE configs[4] at its full network and search shape, few games: 19x19, 256 channels x 20 SE blocks, history 8,
+    800 simulations per move, inference batch 16, top-k 48. Two lockstep moves of 6 games, three ways: batches enqueued
+    without round trips (layer kernels read the row count on the device), one round trip per batch, and every leaf
+    evaluated instead of one row per distinct leaf. Size-independent properties: each game's visit counts sum to 800,
+    pi rows are distributions, the three ways play the same moves with the same pi, and the every-leaf run evaluates
+    800 + 1 rows per game and move."""
+    import torch
+    from alphazero_amd.model import AlphaZeroNet
+    from alphazero_amd.selfplay import BatchedSelfPlay, SelfPlayConfig
+    torch.manual_seed(19)
+    net = AlphaZeroNet(board_size=19, channels=256, num_blocks=20).eval().cuda()
+    cfg = SelfPlayConfig(board_size=19, mcts_simulations=800, mcts_inference_batch=16, mcts_topk_expand=48)
+    runs = {}
+    for tag, use_async, dedup in (("async", True, True), ("sync", False, True), ("every_leaf", True, False)):
+        sp = BatchedSelfPlay(net, cfg, games=6, seed0=40, dedup_leaves=dedup, reuse_roots=False)
+        assert not sp.net.fused and sp.async_search
+        sp.set_async(use_async)
+        sp.begin(num_games=6)
+        for _ in range(2):
+            sp.step()
+        c = sp.counters
+        assert c["sims"] == 2 * 6 * 800 and c["moves"] == 12
+        assert c["nn_rows_nodedup"] == 12 * 801
+        if not dedup:
+            assert c["nn_rows"] == 12 * 801
+        else:
+            assert 12 * (800 // 16 + 1) <= c["nn_rows"] < 12 * 801
+        for bits, caps, pi32, to_play, diff in sp.log:
+            assert pi32.shape == (6, 362) and np.allclose(pi32.sum(axis=1), 1.0, atol=1e-5)
+        board, _, sc, _ = sp.eng.export_state()
+        runs[tag] = ([x[2].copy() for x in sp.log], board.cpu().numpy(), sc.cpu().numpy()[:, :6])
+        st = sp.eng.stats()
+        assert st["sims"] == 6 * 800 and st["max_nodes"] <= 1 + 801 * 48
+    for tag in ("sync", "every_leaf"):
+        for pa, pb in zip(runs["async"][0], runs[tag][0]):
+            assert np.array_equal(pa, pb), tag
+        assert np.array_equal(runs["async"][1], runs[tag][1]) and np.array_equal(runs["async"][2], runs[tag][2]), tag
