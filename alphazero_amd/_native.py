@@ -68,6 +68,7 @@ SIGNATURES = {
     "az_net_reserve": (_I32, [_VP, _I32]),
     "az_net_forward_static": (_I32, [_VP, _VP, _I32, _VP, _VP, _VP]),
     "az_net_static_max_rows": (_I64, [_VP]),
+    "az_net_indirect_passes": (_I32, [_VP, _I32]),
     "az_net_is_fused": (_I32, [_VP, C.POINTER(_I32)]),
     "az_net_forward_indirect": (_I32, [_VP, _VP, _VP, _I32, _VP, _VP, _VP]),
     "az_net_profile_spans": (_I32, [_VP, _VP, C.c_int64, C.POINTER(C.c_int64)]),

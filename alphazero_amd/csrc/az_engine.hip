@@ -664,79 +664,109 @@ __global__ __launch_bounds__(64) void k_leaf(Dev d, void* out, int layout) {
                        (unsigned char*)out + (size_t)r * row_bytes, layout, d.row_legal + (size_t)r * d.A);
 }
 
-// numpy pairwise summation of a contiguous float64 vector (ndarray.sum(), mcts.py:80).
-__device__ inline double pw_block(const double* a, int n) {
-    if (n < 8) {
+// numpy pairwise summation of a contiguous float64 vector (ndarray.sum(), mcts.py:80), n <= 512, by the whole wave with
+// numpy's own addition tree. numpy splits n > 128 in halves (the first rounded down to a multiple of 8) until a piece has
+// at most 128 elements, and sums a piece with eight interleaved accumulators r_j = a[j] + a[8+j] + a[16+j] + ... that
+// are combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), then adds the piece's last n%8 elements one by one. Here lane
+// 8b+j owns accumulator j of piece b (at most 4 pieces for n <= 512), the combination is the xor-1/2/4 butterfly (the
+// same tree: float addition commutes), and the pieces are added in numpy's order. Every lane returns the sum.
+__device__ inline double pw_sum_wave(const double* a, int n, int lane) {
+    if (n < 8) {   // wave-uniform
         double r = 0.0;
         for (int i = 0; i < n; ++i) r += a[i];
         return r;
     }
-    double r0 = a[0], r1 = a[1], r2 = a[2], r3 = a[3], r4 = a[4], r5 = a[5], r6 = a[6], r7 = a[7];
-    int i;
-    for (i = 8; i < n - (n % 8); i += 8) {
-        r0 += a[i]; r1 += a[i + 1]; r2 += a[i + 2]; r3 += a[i + 3];
-        r4 += a[i + 4]; r5 += a[i + 5]; r6 += a[i + 6]; r7 += a[i + 7];
+    // piece boundaries: start[0..np], np in {1, 2, 3, 4}
+    int start[5], np_ = 1;
+    start[0] = 0; start[1] = n;
+    if (n > 128) {
+        int n2 = n / 2; n2 -= n2 % 8;
+        int cuts[3], nc = 0;
+        if (n2 > 128) { int h = n2 / 2; h -= h % 8; cuts[nc++] = h; }
+        const int first_half_cuts = nc;
+        cuts[nc++] = n2;
+        if (n - n2 > 128) { int h = (n - n2) / 2; h -= h % 8; cuts[nc++] = n2 + h; }
+        for (int k = 0; k < nc; ++k) start[k + 1] = cuts[k];
+        start[nc + 1] = n;
+        np_ = nc + 1;
+        (void)first_half_cuts;
     }
-    double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
-    for (; i < n; ++i) res += a[i];
-    return res;
-}
-__device__ inline double pw_l2(const double* a, int n) {
-    if (n <= 128) return pw_block(a, n);
-    int n2 = n / 2;
-    n2 -= n2 % 8;
-    return pw_block(a, n2) + pw_block(a + n2, n - n2);
-}
-__device__ inline double pw_sum(const double* a, int n) {  // n <= 512
-    if (n <= 128) return pw_block(a, n);
-    int n2 = n / 2;
-    n2 -= n2 % 8;
-    return pw_l2(a, n2) + pw_l2(a + n2, n - n2);
+    const int b = lane >> 3, j = lane & 7;
+    double r = 0.0;
+    int len = 0, s0 = 0;
+    if (b < np_) {
+        s0 = start[b]; len = start[b + 1] - s0;
+        if (len >= 8) {
+            r = a[s0 + j];
+            const int lim = len - (len % 8);
+            for (int i = 8; i < lim; i += 8) r += a[s0 + i + j];
+        }
+    }
+    r += __shfl_xor(r, 1);
+    r += __shfl_xor(r, 2);
+    r += __shfl_xor(r, 4);
+    if (b < np_) {
+        if (len < 8) { r = 0.0; for (int i = 0; i < len; ++i) r += a[s0 + i]; }   // a short piece is summed one by one
+        else for (int i = len - (len % 8); i < len; ++i) r += a[s0 + i];
+    }
+    // r of lane 8b = sum of piece b; numpy adds (piece0 + piece1) + (piece2 + piece3) when both halves were split,
+    // (piece0 + piece1) + piece2 or piece0 + (piece1 + piece2) when one was, piece0 + piece1 when none was
+    const double p0 = __shfl(r, 0), p1 = __shfl(r, 8), p2 = __shfl(r, 16), p3 = __shfl(r, 24);
+    if (np_ == 1) return p0;
+    if (np_ == 2) return p0 + p1;
+    if (np_ == 4) return (p0 + p1) + (p2 + p3);
+    int n2 = n / 2; n2 -= n2 % 8;
+    return n2 > 128 ? (p0 + p1) + p2 : p0 + (p1 + p2);
 }
 
 // mcts.py:66-91 + :118-137 for one node: masked softmax (float64), optional noise, top-k, children.
-// p_lds: double[A] work array; runs on the whole wave.
+// p_lds: double[2*A] work arrays (probabilities, ranking keys); runs on the whole wave.
 __device__ inline void expand_node(const Dev& d, int g, int lane, int node, const float* logits, const uint8_t* legal,
-                                   const double* noise, double* p_lds, int* ord_lds, double* priors_out) {
+                                   const double* noise, double* p_lds, double* priors_out) {
     const int A = d.A;
-    __shared__ double s_bcast[2];
+    constexpr int PPA = 6;   // actions per lane: A <= 362
+    double* q_lds = p_lds + A;
+    bool lg_[PPA];
     double mx = -INFINITY;
-    for (int a = lane; a < A; a += 64) {
-        const double m = (double)logits[a] + (legal[a] ? 0.0 : -1e9);
-        p_lds[a] = m;
-        mx = fmax(mx, m);
+    int nl = 0;
+#pragma unroll
+    for (int k = 0; k < PPA; ++k) {
+        const int a = lane + 64 * k;
+        lg_[k] = a < A && legal[a];
+        nl += __popcll(__ballot(lg_[k]));
+        if (a < A) {
+            const double m = (double)logits[a] + (lg_[k] ? 0.0 : -1e9);
+            p_lds[a] = m;
+            mx = fmax(mx, m);
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
-    for (int a = lane; a < A; a += 64) p_lds[a] = exp(p_lds[a] - mx);
-    __syncthreads();
-    if (lane == 0) s_bcast[0] = pw_sum(p_lds, A);
-    __syncthreads();
-    const double sum = s_bcast[0];
-    int nl = 0;
-    for (int a0 = 0; a0 < A; a0 += 64) {
-        const int a = a0 + lane;
-        const bool lg = a < A && legal[a];
-        nl += __popcll(__ballot(lg));
-    }
-    for (int a = lane; a < A; a += 64) {
-        if (sum <= 0) p_lds[a] = legal[a] ? 1.0 / (double)nl : 0.0;
-        else p_lds[a] = p_lds[a] / sum;
+#pragma unroll
+    for (int k = 0; k < PPA; ++k) {
+        const int a = lane + 64 * k;
+        if (a < A) p_lds[a] = exp(p_lds[a] - mx);
     }
     __syncthreads();
+    const double sum = pw_sum_wave(p_lds, A, lane);
+    double pr[PPA];
+#pragma unroll
+    for (int k = 0; k < PPA; ++k) {
+        const int a = lane + 64 * k;
+        pr[k] = 0.0;
+        if (a < A) pr[k] = sum <= 0 ? (lg_[k] ? 1.0 / (double)nl : 0.0) : p_lds[a] / sum;
+    }
     if (noise) {  // mcts.py:121-124: noise[i] belongs to the i-th legal action
         int base = 0;
-        for (int a0 = 0; a0 < A; a0 += 64) {
-            const int a = a0 + lane;
-            const bool lg = a < A && legal[a];
-            const unsigned long long bal = __ballot(lg);
-            if (lg) {
+#pragma unroll
+        for (int k = 0; k < PPA; ++k) {
+            const unsigned long long bal = __ballot(lg_[k]);
+            if (lg_[k]) {
                 const int i = base + __popcll(bal & ((1ull << lane) - 1ull));
-                p_lds[a] = d.one_minus_eps * p_lds[a] + d.eps * noise[i];
+                pr[k] = d.one_minus_eps * pr[k] + d.eps * noise[i];
             }
             base += __popcll(bal);
         }
-        __syncthreads();
     }
     if (priors_out)
         for (int a = lane; a < A; a += 64) priors_out[a] = 0.0;
@@ -755,50 +785,69 @@ __device__ inline void expand_node(const Dev& d, int g, int lane, int node, cons
         first = __shfl(first, 0);
         if (first < 0) return;
     }
-    const size_t nbase = (size_t)g * d.max_nodes;
-    int base = 0;
-    for (int a0 = 0; a0 < A; a0 += 64) {
-        const int a = a0 + lane;
-        const bool lg = a < A && legal[a];
-        const unsigned long long bal = __ballot(lg);
-        if (lg) {
-            int pos;
-            if (!topk) {
-                pos = base + __popcll(bal & ((1ull << lane) - 1ull));
-            } else {
-                const double pa = p_lds[a];
-                int rank = 0;
-                for (int x = 0; x < A; ++x) {
-                    if (!legal[x]) continue;
-                    const double px = p_lds[x];
-                    rank += (px > pa || (px == pa && x < a)) ? 1 : 0;
-                }
-                pos = rank;
-                if (a == A - 1 && rank >= cnt) pos = cnt - 1;  // pass replaces the last kept action
-                else if (rank >= cnt) pos = -1;
-                else if (rank == cnt - 1) {  // am I displaced by the pass?
-                    const double pp = p_lds[A - 1];
-                    int prank = 0;
-                    for (int x = 0; x < A - 1; ++x) {
-                        if (!legal[x]) continue;
-                        const double px = p_lds[x];
-                        prank += (px > pp || px == pp) ? 1 : 0;
-                    }
-                    if (prank >= cnt) pos = -1;
-                }
+    int pos[PPA];
+    if (!topk) {
+        int base = 0;
+#pragma unroll
+        for (int k = 0; k < PPA; ++k) {
+            const unsigned long long bal = __ballot(lg_[k]);
+            pos[k] = lg_[k] ? base + __popcll(bal & ((1ull << lane) - 1ull)) : -1;
+            base += __popcll(bal);
+        }
+    } else {
+        // ranking keys: the prior of a legal action, -1 for an illegal one (priors are >= 0, so those never count)
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < PPA; ++k) {
+            const int a = lane + 64 * k;
+            if (a < A) q_lds[a] = lg_[k] ? pr[k] : -1.0;
+        }
+        __syncthreads();
+        int rank[PPA];
+#pragma unroll
+        for (int k = 0; k < PPA; ++k) rank[k] = 0;
+        const int kmax = (A + 63) / 64;   // wave-uniform
+        for (int x = 0; x < A; ++x) {     // q_lds[x]: one broadcast read serves every lane and every k
+            const double px = q_lds[x];
+#pragma unroll
+            for (int k = 0; k < PPA; ++k)
+                if (k < kmax) rank[k] += (px > pr[k] || (px == pr[k] && x < lane + 64 * k)) ? 1 : 0;
+        }
+        // the pass (action A-1) is forced in: if it ranks outside the K kept, it takes the last slot and the action that
+        // ranked K-1 is dropped. prank = legal stone moves with prior >= the pass's = the pass's rank among the stones
+        const double pp = q_lds[A - 1];
+        int prank = 0;
+#pragma unroll
+        for (int k = 0; k < PPA; ++k) {
+            const int a = lane + 64 * k;
+            prank += __popcll(__ballot(lg_[k] && a < A - 1 && pr[k] >= pp));
+        }
+#pragma unroll
+        for (int k = 0; k < PPA; ++k) {
+            const int a = lane + 64 * k;
+            int ps = -1;
+            if (lg_[k]) {
+                ps = rank[k];
+                if (a == A - 1 && rank[k] >= cnt) ps = cnt - 1;
+                else if (rank[k] >= cnt) ps = -1;
+                else if (rank[k] == cnt - 1 && a != A - 1 && prank >= cnt) ps = -1;
             }
-            if (pos >= 0) {
-                if (priors_out) priors_out[a] = p_lds[a];
-                if (!already) {
-                    const size_t c = nbase + first + pos;
-                    d.prior[c] = p_lds[a]; d.vsum[c] = 0.0; d.visits[c] = 0; d.action[c] = (int16_t)a;
-                    d.child_off[c] = 0; d.n_child[c] = 0;
-                }
+            pos[k] = ps;
+        }
+    }
+    const size_t nbase = (size_t)g * d.max_nodes;
+#pragma unroll
+    for (int k = 0; k < PPA; ++k) {
+        const int a = lane + 64 * k;
+        if (pos[k] >= 0) {
+            if (priors_out) priors_out[a] = pr[k];
+            if (!already) {
+                const size_t c = nbase + first + pos[k];
+                d.prior[c] = pr[k]; d.vsum[c] = 0.0; d.visits[c] = 0; d.action[c] = (int16_t)a;
+                d.child_off[c] = 0; d.n_child[c] = 0;
             }
         }
-        base += __popcll(bal);
     }
-    (void)ord_lds;
     if (!already && lane == 0) {
         d.child_off[nbase + node] = first;
         d.n_child[nbase + node] = (int16_t)cnt;
@@ -817,7 +866,7 @@ __global__ __launch_bounds__(64) void k_expand_root(Dev d, const float* logits, 
     const int r = d.row_off[g];
     const float* lg = (d.rc_cap && d.root_cached[g]) ? d.root_logits + (size_t)g * d.A : logits + (size_t)r * d.A;
     expand_node(d, g, lane, 0, lg, d.row_legal + (size_t)r * d.A,
-                noise ? noise + (size_t)g * d.A : nullptr, p_lds, nullptr, priors_out ? priors_out + (size_t)r * d.A : nullptr);
+                noise ? noise + (size_t)g * d.A : nullptr, p_lds, priors_out ? priors_out + (size_t)r * d.A : nullptr);
 }
 
 // Expand the batch's leaves, then revert virtual loss and back up in slot order (mcts.py:203-218).
@@ -825,17 +874,22 @@ __global__ __launch_bounds__(64) void k_expand_backup(Dev d, const float* logits
                                                       double* priors_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
     double* p_lds = (double*)dyn;
+    double* s_val = p_lds + 2 * d.A;          // [B] value each slot backs up
+    int* s_len = (int*)(s_val + d.B);         // [B] path length
+    int* s_n1 = s_len + d.B;                  // [B] path[1] (the root child), -1 for a path that ends at the root
     const int g = blockIdx.x, lane = threadIdx.x;
     if (!d.active[g]) return;
     const int nu = d.n_unique[g], r0 = d.row_off[g];
+    const size_t nb = (size_t)g * d.max_nodes;
     for (int u = 0; u < nu; ++u) {
         const int slot = d.uniq_slot[g * d.B + u];
+        const int plen = d.path_len[g * d.B + slot];
         const int* path = d.path + ((size_t)g * d.B + slot) * d.max_depth;
-        const int node = path[d.path_len[g * d.B + slot] - 1];
+        const int node = path[plen - 1];
         expand_node(d, g, lane, node, logits + (size_t)(r0 + u) * d.A, d.row_legal + (size_t)(r0 + u) * d.A, nullptr, p_lds,
-                    nullptr, priors_out ? priors_out + (size_t)(r0 + u) * d.A : nullptr);
-        if (d.rc_cap && d.path_len[g * d.B + slot] == 2) {   // a child of the root: a candidate for the next root
-            const int ci = node - d.child_off[(size_t)g * d.max_nodes];
+                    priors_out ? priors_out + (size_t)(r0 + u) * d.A : nullptr);
+        if (d.rc_cap && plen == 2) {   // a child of the root: a candidate for the next root
+            const int ci = node - d.child_off[nb];
             if (ci >= 0 && ci < d.rc_cap) {
                 float* dst = d.rc_logits + ((size_t)g * d.rc_cap + ci) * d.A;
                 for (int i = lane; i < d.A; i += 64) dst[i] = logits[(size_t)(r0 + u) * d.A + i];
@@ -843,11 +897,11 @@ __global__ __launch_bounds__(64) void k_expand_backup(Dev d, const float* logits
             }
         }
     }
-    const size_t nb = (size_t)g * d.max_nodes;
     double* vsum = d.vsum + nb;
     int* visits = d.visits + nb;
-    for (int slot = 0; slot < batch_n; ++slot) {
-        const int gs = g * d.B + slot;
+    // Per-slot facts, fetched by the lanes side by side (one dependent chain instead of one per slot)
+    for (int s = lane; s < batch_n; s += 64) {
+        const int gs = g * d.B + s;
         const int ref = d.leaf_ref[gs];
         double value;
         if (ref < 0) value = d.term_value[gs];
@@ -857,18 +911,54 @@ __global__ __launch_bounds__(64) void k_expand_backup(Dev d, const float* logits
             value = (double)values[r0 + u];
         }
         const int len = d.path_len[gs];
-        const int* path = d.path + (size_t)gs * d.max_depth;
-        for (int i = lane; i < len; i += 64) {
-            const int pn = path[i];
-            int vc = visits[pn];
-            double vs = vsum[pn];
-            if (d.vl > 0.0) { vc -= 1; vs += d.vl; }
-            const double v = ((len - 1 - i) & 1) ? -value : value;
-            visits[pn] = vc + 1;
-            vsum[pn] = vs + v;
+        s_val[s] = value;
+        s_len[s] = len;
+        s_n1[s] = len > 1 ? d.path[(size_t)gs * d.max_depth + 1] : -1;
+    }
+    __syncthreads();
+    // The root and its children (lane i: child i, when there are at most 64) keep their statistics in registers over the
+    // slots: every path starts there and, with virtual loss, most end there. Deeper nodes are updated in memory.
+    const int rnc = d.n_child[nb], rfirst = d.child_off[nb];
+    const bool cached = rnc > 0 && rnc <= 64;
+    double c_vsum = 0.0, r_vsum = vsum[0];
+    int c_vis = 0, r_vis = visits[0];
+    if (cached && lane < rnc) { c_vsum = vsum[rfirst + lane]; c_vis = visits[rfirst + lane]; }
+    const bool vl_on = d.vl > 0.0;
+    for (int slot = 0; slot < batch_n; ++slot) {
+        const double value = s_val[slot];
+        const int len = s_len[slot];
+        if (cached) {
+            {   // root (i = 0)
+                const double v = ((len - 1) & 1) ? -value : value;
+                int vc = r_vis; double vs = r_vsum;
+                if (vl_on) { vc -= 1; vs += d.vl; }
+                r_vis = vc + 1; r_vsum = vs + v;
+            }
+            if (len > 1 && lane == s_n1[slot] - rfirst) {   // the root child (i = 1)
+                const double v = ((len - 2) & 1) ? -value : value;
+                int vc = c_vis; double vs = c_vsum;
+                if (vl_on) { vc -= 1; vs += d.vl; }
+                c_vis = vc + 1; c_vsum = vs + v;
+            }
         }
-        __threadfence_block();
-        __syncthreads();
+        if (!cached || len > 2) {
+            const int* path = d.path + ((size_t)g * d.B + slot) * d.max_depth;
+            for (int i = (cached ? 2 : 0) + lane; i < len; i += 64) {
+                const int pn = path[i];
+                int vc = visits[pn];
+                double vs = vsum[pn];
+                if (vl_on) { vc -= 1; vs += d.vl; }
+                const double v = ((len - 1 - i) & 1) ? -value : value;
+                visits[pn] = vc + 1;
+                vsum[pn] = vs + v;
+            }
+            __threadfence_block();
+            __syncthreads();
+        }
+    }
+    if (cached) {
+        if (lane < rnc) { visits[rfirst + lane] = c_vis; vsum[rfirst + lane] = c_vsum; }
+        if (lane == 0) { visits[0] = r_vis; vsum[0] = r_vsum; }
     }
 }
 
@@ -1225,7 +1315,7 @@ int az_mcts_row_games(az_engine* e, int32_t* row_game, void* stream) {
 
 int az_mcts_expand(az_engine* e, const float* logits, const float* values, const double* noise, void* stream) {
     if (!e) return fail(AZ_ERR_ARG, "null engine");
-    const size_t shmem = (size_t)e->d.A * 8 + 64;
+    const size_t shmem = (size_t)e->d.A * 16 + (size_t)e->d.B * 16 + 64;
     if (e->phase == PH_ROOT) {
         if (!logits && !(e->d.rc_cap && e->rows_known && e->pending_rows == 0)) return fail(AZ_ERR_ARG, "null logits");
         hipLaunchKernelGGL(k_expand_root, dim3(e->d.G), dim3(64), shmem, (hipStream_t)stream, e->d, logits, noise, e->last_priors);

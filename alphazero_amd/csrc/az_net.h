@@ -46,5 +46,6 @@ int mfma_forward(MfmaNet* m, const void* feat_bf16_nhwc, int rows, const int* ro
 int mfma_reserve(MfmaNet* m, int rows);
 int mfma_forward_static(MfmaNet* m, const void* feat_bf16_nhwc, int rows, float* logits, float* values, hipStream_t st);
 long long mfma_static_max_rows(const MfmaNet* m);
+int mfma_indirect_passes(const MfmaNet* m, int max_rows);
 
 }  // namespace az

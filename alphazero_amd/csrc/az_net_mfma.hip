@@ -1097,6 +1097,14 @@ static int fused_forward(MfmaNet* m, const void* feat, int rows, const int* rows
     return AZ_OK;
 }
 
+// Launch sequences an indirect forward over `max_rows` rows makes: 1 for the fused tower; for the layer path one per chunk
+// of the upper bound (each pass past the live rows costs its empty launches).
+int mfma_indirect_passes(const MfmaNet* m, int max_rows) {
+    if (!m->layers) return 1;
+    const int chunk = layers_chunk_boards(m->layers);
+    return (max_rows + chunk - 1) / chunk;
+}
+
 // rows_dev == null: `rows` positions. rows_dev != null: *rows_dev positions (read on the device, at most `rows`).
 int mfma_forward(MfmaNet* m, const void* feat, int rows, const int* rows_dev, float* logits, float* values, hipStream_t st) {
     const az_net_config& c = m->cfg;

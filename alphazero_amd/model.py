@@ -175,6 +175,10 @@ class NativeNet:
         with torch.cuda.device(self.device):
             N.check(self.L.az_net_reserve(self._h, int(rows)), "az_net_reserve")
 
+    def indirect_passes(self, max_rows: int) -> int:
+        """Launch sequences forward_indirect makes for an upper bound of max_rows (1: no empty chunk passes)."""
+        return int(self.L.az_net_indirect_passes(self._h, int(max_rows)))
+
     def static_max_rows(self) -> int:
         return int(self.L.az_net_static_max_rows(self._h))
 

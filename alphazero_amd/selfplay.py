@@ -178,8 +178,10 @@ class _Lane:
             self.root_reuse = self.net is not None and precision == "bf16" and owner.reuse_roots
             if self.root_reuse:
                 self.eng.set_root_reuse(True)
-            # with the native bf16 network the batches of a search are enqueued without host round trips
-            self.async_search = self.net is not None and precision == "bf16" and self.net.indirect
+            # with the native bf16 network the batches of a search are enqueued without host round trips, unless the
+            # layer-by-layer path would pay for empty chunk passes over the upper bound (then: one round trip per batch)
+            self.can_async = self.net is not None and precision == "bf16" and self.net.indirect
+            self.async_search = self.can_async and self.net.indirect_passes(self.max_rows) == 1
             if self.net is not None and precision == "bf16":
                 self.net.reserve(self.max_rows)      # no allocation inside the move loop
             if self.async_search:
@@ -403,7 +405,7 @@ class BatchedSelfPlay:
     def set_async(self, enable: bool):
         """Switch between enqueueing the batches of a search without host round trips and one round trip per batch."""
         for ln in self.lanes:
-            ok = bool(enable) and ln.net is not None and ln.layout == N.AZ_FEAT_BF16_NHWC and ln.net.indirect
+            ok = bool(enable) and ln.can_async
             ln.async_search = ok
             ln.eng.set_async(ok)
 

@@ -186,6 +186,11 @@ int az_net_forward_static(az_net* net, const void* feat_dev, int32_t rows, float
                           void* stream);
 int64_t az_net_static_max_rows(const az_net* net);
 
+/* How many launch sequences az_net_forward_indirect makes for an upper bound of max_rows: 1 for a fused network; a
+ * layer-by-layer network runs one sequence per chunk of the bound, and the sequences past the live rows are empty
+ * launches that still cost their dispatch, so a caller may prefer one host round trip per batch when this exceeds 1. */
+int az_net_indirect_passes(const az_net* net, int32_t max_rows);
+
 /* Timing of the dominant kernel (the fused tower) with HIP events recorded on the launch stream.
  * If the three output pointers are non-NULL they receive the total milliseconds, launch count and
  * row count accumulated since profiling was last enabled (synchronises on the recorded events);

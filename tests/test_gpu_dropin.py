@@ -370,7 +370,7 @@ def test_config5_shape_lockstep_moves():
     without round trips (layer kernels read the row count on the device), one round trip per batch, and every leaf
     evaluated instead of one row per distinct leaf. Size-independent properties: each game's visit counts sum to 800,
     pi rows are distributions, the three ways play the same moves with the same pi, and the every-leaf run evaluates
-    800 + 1 rows per game and move."""
+    one row per simulation that does not end in a terminal leaf, plus the root."""
     import torch
     from alphazero_amd.model import AlphaZeroNet
     from alphazero_amd.selfplay import BatchedSelfPlay, SelfPlayConfig
@@ -380,16 +380,16 @@ def test_config5_shape_lockstep_moves():
     runs = {}
     for tag, use_async, dedup in (("async", True, True), ("sync", False, True), ("every_leaf", True, False)):
         sp = BatchedSelfPlay(net, cfg, games=6, seed0=40, dedup_leaves=dedup, reuse_roots=False)
-        assert not sp.net.fused and sp.async_search
+        assert not sp.net.fused and sp.async_search          # 96 rows at most: one chunk, no empty passes
         sp.set_async(use_async)
         sp.begin(num_games=6)
         for _ in range(2):
             sp.step()
         c = sp.counters
         assert c["sims"] == 2 * 6 * 800 and c["moves"] == 12
-        assert c["nn_rows_nodedup"] == 12 * 801
+        assert 12 * 801 - 12 * 16 <= c["nn_rows_nodedup"] <= 12 * 801        # leaves after two passes are terminal: no row
         if not dedup:
-            assert c["nn_rows"] == 12 * 801
+            assert c["nn_rows"] == c["nn_rows_nodedup"]
         else:
             assert 12 * (800 // 16 + 1) <= c["nn_rows"] < 12 * 801
         for bits, caps, pi32, to_play, diff in sp.log:
