@@ -422,31 +422,41 @@ __device__ __forceinline__ void gemm_conv_gw(f32x4 (&acc)[MI][NI], const uint4* 
     };
     int apc[MI], apn[MI];
     tap_offsets(apc, 0);
-    bf16x8 a[2][MI], b[DEPTH + 1][NI];
-    static_assert(KPT % 2 == 0 && (KPT % (DEPTH + 1) == 0 || DEPTH == 1), "the fragment rings must keep static indices across taps");
+    // One set of activation fragments, refilled as it drains: the NI MFMAs that consume fragment mi are followed at once by
+    // the LDS read of the next k-step's fragment mi into the same registers, so every read has (MI-1)*NI MFMAs of cover
+    // and the registers a second set would take stay free. The issue order is pinned (NI MFMAs, one LDS read, and one of
+    // the k-step's NI weight loads after each of the first NI groups): left to itself the scheduler sinks the reads to
+    // the end of the k-step and the first MFMA of the next one waits for LDS.
+    bf16x8 a[MI], b[DEPTH + 1][NI];
+    static_assert(KPT % 2 == 0 && (KPT % (DEPTH + 1) == 0 || DEPTH == 1), "the fragment ring must keep static indices across taps");
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) b[d][ni] = wfrag(d, ni);
     __syncthreads();   // the activation image is complete
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) a[0][mi] = *(const bf16x8*)(act + apc[mi]);
+    for (int mi = 0; mi < MI; ++mi) a[mi] = *(const bf16x8*)(act + apc[mi]);
     int s = 0;
     for (int tap = 0; tap < ntaps; ++tap) {
         tap_offsets(apn, tap + 1);
 #pragma unroll
         for (int u = 0; u < KPT; ++u, ++s) {
             constexpr int NB = DEPTH + 1;
-            const int cur = u % 2, nxt = 1 - cur, bc = u % NB, bn = (u + DEPTH) % NB;
+            const int bc = u % NB, bn = (u + DEPTH) % NB;
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) b[bn][ni] = wfrag(s + DEPTH, ni);
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-                a[nxt][mi] = u + 1 < KPT ? *(const bf16x8*)(act + apc[mi] + (u + 1) * 64) : *(const bf16x8*)(act + apn[mi]);
+            for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
+                for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[bc][ni], a[mi], acc[mi][ni], 0, 0, 0);
+                a[mi] = u + 1 < KPT ? *(const bf16x8*)(act + apc[mi] + (u + 1) * 64) : *(const bf16x8*)(act + apn[mi]);
+            }
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[bc][ni], a[cur][mi], acc[mi][ni], 0, 0, 0);
+            for (int mi = 0; mi < MI; ++mi) {
+                __builtin_amdgcn_sched_group_barrier(0x008, NI, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                if (mi < NI) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);   // keep the loads of later k-steps from being hoisted here (registers)
         }
 #pragma unroll
