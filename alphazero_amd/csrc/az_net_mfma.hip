@@ -112,8 +112,9 @@ __device__ __forceinline__ void store_act(const f32x4 (&acc)[MI][NI], const floa
             for (int r = 0; r < 4; ++r) { v[r] = acc[mi][e][r] + bv[r]; if (RELU) v[r] = fmaxf(v[r], 0.f); }
             const uint2 pk = make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
             *(uint2*)(act + (row_base + mi * 16 + lr) * STRIDE + ch4 * 2) = pk;
-            if (KEEP) {   // two tile rows share one 16-byte slot of the residual scratch
+            if (KEEP) {   // two tile rows share one 16-byte slot of the residual scratch (an odd last row has one to itself)
                 if (mi & 1) xr[(size_t)(MI * P2 + mi / 2) * NT] = make_uint4(hold.x, hold.y, pk.x, pk.y);
+                else if (mi == MI - 1) xr[(size_t)(MI * P2 + mi / 2) * NT] = make_uint4(pk.x, pk.y, 0, 0);
                 else hold = pk;
             }
         }
@@ -272,6 +273,7 @@ __device__ __forceinline__ void residual_store(const f32x4 (&acc)[MI][NI], const
             *(uint2*)(act + (row_base + mi * 16 + lr) * STRIDE + ch4 * 2) = pk;
             if (keep) {
                 if (mi & 1) xr[(size_t)(MI * P2 + mi / 2) * NT] = make_uint4(hold.x, hold.y, pk.x, pk.y);
+                else if (mi == MI - 1) xr[(size_t)(MI * P2 + mi / 2) * NT] = make_uint4(pk.x, pk.y, 0, 0);
                 else hold = pk;
             }
         }
@@ -284,18 +286,21 @@ __device__ __forceinline__ void residual_store(const f32x4 (&acc)[MI][NI], const
 // (LDS-bound), striding over the board groups.
 // GW > 0: the residual blocks' convolutions read their weight fragments straight from global memory, GW k-steps
 // ahead (gemm_conv_gw: no LDS staging, no barrier inside the loop).
-template <int C, int WM, int WN, int NH, int GW = 0>
+// ROWS: positions a workgroup holds (256: TB = 256/np boards; 96: the low-latency variant for small batches, one 9x9 board
+// per workgroup, so that a handful of positions spreads over as many compute units instead of queueing on one).
+template <int C, int WM, int WN, int NH, int GW = 0, int ROWS = 256>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_tower(TowerParams P) {
     constexpr int NW = WM * WN, NT = 64 * NW;
-    constexpr int MI = 256 / (WM * 16), NI = C / (WN * 16);
-    constexpr int MIH = 256 / (NW * 16), NIH = NH / 16;
+    constexpr int MI = ROWS / (WM * 16), NI = C / (WN * 16);
+    constexpr int MIH = (ROWS + NW * 16 - 1) / (NW * 16), NIH = NH / 16;   // head: the waves split the row tiles; waves past ROWS compute zeros
     constexpr int STRIDE = 2 * C + 32;
-    constexpr int NV = (MI * NI + 1) / 2;  // 16-byte vectors of packed bf16 residual per thread
-    static_assert(NIH % 2 == 0 && (NI % 2 == 0 || MI % 2 == 0), "channel tiles are stored in pairs (an unpaired last tile needs an even MI)");
+    constexpr int NV = MI * (NI / 2) + ((NI & 1) ? (MI + 1) / 2 : 0);  // 16-byte vectors of packed bf16 residual per thread
+    static_assert(ROWS % (WM * 16) == 0 && NIH % 2 == 0, "whole row tiles per wave; head channel tiles are stored in pairs");
+    static_assert(NW * 16 * MIH * (2 * NH + 16) <= ROWS * STRIDE, "the head activations of every wave's row tiles must fit the activation image");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* act = smem;
     constexpr int ZBYTES = ((256 + 2 * C + 16 + 127) / 128) * 128;   // zero region, see gemm_conv
-    char* zrow = smem + ((256 * STRIDE + 255) / 256) * 256;
+    char* zrow = smem + ((ROWS * STRIDE + 255) / 256) * 256;
     char* bbuf = zrow + ZBYTES;
     float* scratch = (float*)bbuf;  // epilogue scratch shares the weight staging buffers
     const int tid = threadIdx.x;
@@ -320,7 +325,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_tower(TowerPara
         {
             const int ppr = P.cin_pad * 2 / 16;  // 16-byte pieces per row
             const uint4* src = (const uint4*)(P.feat + (size_t)board0 * P.np * P.cin_pad);
-            for (int i = tid; i < 256 * ppr; i += NT) {
+            for (int i = tid; i < ROWS * ppr; i += NT) {
                 const int row = i / ppr, part = i - row * ppr;
                 uint4 v = make_uint4(0, 0, 0, 0);
                 if (row < g.vrows) v = src[i];
@@ -652,8 +657,10 @@ struct MfmaNet {
     float* vpart = nullptr;       // split value tail: [chunk rows][shares] partial sums, allocated with hq (layer path, large boards)
     uint4* xres = nullptr;   // residual-stream scratch for max_grid workgroups
     int max_grid = 0;
+    int cus = 256;                // compute units of the device
     std::vector<void*> retired;   // scratch buffers that were replaced by larger ones: launches already enqueued may still use
                                   // them, so they are only freed with the network (sizes grow geometrically: bounded waste)
+    int TB_small = 0;             // boards per workgroup of the 96-row low-latency variant (0: this shape has none)
     int split = 0;                // 0: 4x2 waves, weights through LDS; 1: 2x4 waves, weight fragments from global memory (C = 192)
     LayerNet* layers = nullptr;   // set instead of the fused tower's weights when the shape needs the layer-by-layer path
     // optional timing of the tower kernel with HIP events on the launch stream
@@ -688,12 +695,12 @@ static size_t se_blob_bytes(int C, int hid) {  // per block: w1, w2^T (bf16), b1
 // LDS: activations, zero row, then a region shared by the two weight staging buffers and the
 // squeeze-excite scratch (pooled [TB][C], hidden [TB][hid], scale [TB][C],
 // the block's SE weights).
-static size_t tower_lds_bytes(int C, int NH, int TB, int hid) {
+static size_t tower_lds_bytes(int C, int NH, int TB, int hid, int rows = 256) {
     const size_t stride = 2 * C + 32;
     const size_t tile = (size_t)64 * std::max(C, NH) * 2;
     const size_t se = ((size_t)2 * TB * C + (size_t)TB * hid) * 4 + 16 + se_blob_bytes(C, hid);
     const size_t zbytes = ((256 + 2 * (size_t)C + 16 + 127) / 128) * 128;
-    return ((256 * stride + 255) / 256) * 256 + zbytes + std::max(2 * tile, se);
+    return (((size_t)rows * stride + 255) / 256) * 256 + zbytes + std::max(2 * tile, se);
 }
 
 int mfma_create(const az_net_config& c, const NetLayout& L, const float* Pm, MfmaNet** out) {
@@ -709,6 +716,10 @@ int mfma_create(const az_net_config& c, const NetLayout& L, const float* Pm, Mfm
     const bool fused = fused_supported(c);
     m->split = C >= 128 ? 1 : 0;   // measured: 192 ch +3 %, 128 ch +5 %, 64 ch -3 %
     if (const char* sp = getenv("AZ_TOWER_SPLIT")) m->split = (C >= 64 && atoi(sp) == 1) ? 1 : 0;   // 0 selects the LDS-staged variant
+    // the 96-row variant shares the 2x4-wave kernels' weight images: 128 / 192 channels in their default (global-weights)
+    // form, boards of at most 96 points; AZ_TOWER_SMALL=0 switches it off
+    m->TB_small = (fused && m->split == 1 && (C == 128 || C == 192) && np <= 96) ? 96 / np : 0;
+    if (const char* sm = getenv("AZ_TOWER_SMALL")) if (atoi(sm) == 0) m->TB_small = 0;
     const int tiles_per_wave = C / 64;              // 2x4 waves: C/4 channels each
     const int slab_tiles = (m->split == 1 && (tiles_per_wave & 1)) ? tiles_per_wave : 0;   // channel tiles per wave when that count is odd
     if (fused && tower_lds_bytes(C, m->NH, m->TB, c.se_hidden) > 160 * 1024) { delete m; return fail(AZ_ERR_ARG, "bf16 MFMA path: LDS budget exceeded"); }
@@ -839,10 +850,16 @@ int mfma_create(const az_net_config& c, const NetLayout& L, const float* Pm, Mfm
         case 128:
             e = hipFuncSetAttribute((const void*)k_tower<128, 4, 2, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_tower<128, 2, 4, 64, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e == hipSuccess && m->TB_small)
+                e = hipFuncSetAttribute((const void*)k_tower<128, 2, 4, 64, 1, 96>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)tower_lds_bytes(C, m->NH, m->TB_small, c.se_hidden, 96));
             break;
         case 192:
             e = hipFuncSetAttribute((const void*)k_tower<192, 4, 2, 96>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_tower<192, 2, 4, 96, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e == hipSuccess && m->TB_small)
+                e = hipFuncSetAttribute((const void*)k_tower<192, 2, 4, 96, 2, 96>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)tower_lds_bytes(C, m->NH, m->TB_small, c.se_hidden, 96));
             break;
     }
     if (e != hipSuccess) { mfma_destroy(m); return fail(AZ_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); }
@@ -855,6 +872,7 @@ int mfma_create(const az_net_config& c, const NetLayout& L, const float* Pm, Mfm
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, c.device) != hipSuccess) { mfma_destroy(m); return fail(AZ_ERR_HIP, "hipGetDeviceProperties"); }
         m->max_grid = std::max(1, prop.multiProcessorCount);
+        m->cus = m->max_grid;
         if (hipMalloc((void**)&m->xres, (size_t)m->max_grid * 256 * (size_t)C * 2) != hipSuccess) { mfma_destroy(m); return fail(AZ_ERR_HIP, "hipMalloc (residual scratch)"); }
     } else {   // layer path: head activations (and value-tail shares) of one chunk, sized once
         int rcr = mfma_reserve(m, layers_chunk_boards(m->layers));
@@ -1035,7 +1053,13 @@ static int fused_forward(MfmaNet* m, const void* feat, int rows, const int* rows
     P.hq = hq;
     P.stamps = nullptr;
     P.xres = xres;
-    P.items = (rows + m->TB - 1) / m->TB;
+    // Few positions: the 96-row variant gives every TB_small boards a workgroup of their own, so they spread over the
+    // compute units instead of queueing three boards deep on a few. It wins while its workgroups fit two rounds
+    // (a round takes about 0.4 of a 256-row round); `rows` is the upper bound when the count lives on the device.
+    const bool small = m->TB_small > 0 && (rows + m->TB_small - 1) / m->TB_small <= 2 * m->cus;
+    const int TB = small ? m->TB_small : m->TB;
+    P.TB = TB;
+    P.items = (rows + TB - 1) / TB;
     P.rows_dev = rows_dev;
     const int grid = std::min(P.items, grid_cap);
 #ifdef AZ_STAMP
@@ -1048,7 +1072,7 @@ static int fused_forward(MfmaNet* m, const void* feat, int rows, const int* rows
     }
     P.stamps = stamp_dev;
 #endif
-    const size_t lds = tower_lds_bytes(C, m->NH, m->TB, c.se_hidden);
+    const size_t lds = tower_lds_bytes(C, m->NH, TB, c.se_hidden, small ? 96 : 256);
     std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
     if (timed) {
         int rcp = prof_begin(m, rows_dev ? 0 : rows, st, &ev);   // indirect launches: the caller knows the row total
@@ -1061,11 +1085,13 @@ static int fused_forward(MfmaNet* m, const void* feat, int rows, const int* rows
             else hipLaunchKernelGGL((k_tower<64, 4, 2, 32>), dim3(grid), dim3(512), lds, st, P);
             break;
         case 128:
-            if (m->split == 1) hipLaunchKernelGGL((k_tower<128, 2, 4, 64, 1>), dim3(grid), dim3(512), lds, st, P);
+            if (small) hipLaunchKernelGGL((k_tower<128, 2, 4, 64, 1, 96>), dim3(grid), dim3(512), lds, st, P);
+            else if (m->split == 1) hipLaunchKernelGGL((k_tower<128, 2, 4, 64, 1>), dim3(grid), dim3(512), lds, st, P);
             else hipLaunchKernelGGL((k_tower<128, 4, 2, 64>), dim3(grid), dim3(512), lds, st, P);
             break;
         case 192:
-            if (m->split == 1) hipLaunchKernelGGL((k_tower<192, 2, 4, 96, 2>), dim3(grid), dim3(512), lds, st, P);
+            if (small) hipLaunchKernelGGL((k_tower<192, 2, 4, 96, 2, 96>), dim3(grid), dim3(512), lds, st, P);
+            else if (m->split == 1) hipLaunchKernelGGL((k_tower<192, 2, 4, 96, 2>), dim3(grid), dim3(512), lds, st, P);
             else hipLaunchKernelGGL((k_tower<192, 4, 2, 96>), dim3(grid), dim3(512), lds, st, P);
             break;
         default: return fail(AZ_ERR_ARG, "unsupported channel count");

@@ -135,21 +135,36 @@ class GoState:
         return [int(a) for a in np.nonzero(self._evaluated()["legal"])[0]]
 
     def play(self, move) -> "GoState":                      # go.py:159-203
+        """One upload per call: the move is checked by the device (its status stands in for go.py:179-180's is_legal
+        call unless this state's legal mask is already cached), and while the new position is still resident its legal
+        mask, feature planes and score are read back into the new state's cache, so the caller's next is_legal /
+        legal_actions / to_tensor / winner on it costs nothing."""
         n, h = self.board_size, self.history_len
-        if move is not None and not self.is_legal(move):
-            raise ValueError(f"Illegal move: {move}")
+        if move is not None:
+            r, c = move
+            if not self.in_bounds(r, c) or self.board[r, c] != EMPTY or \
+                    ("legal" in self._cache and not self._cache["legal"][r * n + c]):
+                raise ValueError(f"Illegal move: {move}")
         with _ENGINE_LOCK:
             eng = self._upload()
-            eng.play([encode_action(n, move)])
+            status = eng.play([encode_action(n, move)], raise_on_illegal=False)
+            if int(status.cpu()[0]) != 0:
+                raise ValueError(f"Illegal move: {move}")
             board, hist, sc, seen = (t.cpu().numpy() for t in eng.export_state())
+            score, info = eng.status()
+            cache = {"legal": eng.legal_mask().cpu().numpy()[0].astype(bool), "tensor": eng.features().cpu().numpy()[0],
+                     "score": tuple(float(x) for x in score.cpu().numpy()[0])}
+            cache["winner"] = int(info.cpu().numpy()[0, 7])
         sc = sc[0]
         nh = int(sc[6])
-        return GoState(board=board[0].reshape(n, n).copy(), to_play=int(sc[0]), consecutive_passes=int(sc[1]),
-                       move_count=int(sc[2]), komi=self.komi, history_len=h,
-                       board_history=tuple(hist[0, i].reshape(n, n).copy() for i in range(nh)),
-                       seen_hashes=frozenset(int(x) for x in seen[0, : int(sc[7])].view(np.uint64)),
-                       black_captures=int(sc[3]), white_captures=int(sc[4]),
-                       last_move=None if sc[5] < 0 else divmod(int(sc[5]), n))
+        new = GoState(board=board[0].reshape(n, n).copy(), to_play=int(sc[0]), consecutive_passes=int(sc[1]),
+                      move_count=int(sc[2]), komi=self.komi, history_len=h,
+                      board_history=tuple(hist[0, i].reshape(n, n).copy() for i in range(nh)),
+                      seen_hashes=frozenset(int(x) for x in seen[0, : int(sc[7])].view(np.uint64)),
+                      black_captures=int(sc[3]), white_captures=int(sc[4]),
+                      last_move=None if sc[5] < 0 else divmod(int(sc[5]), n))
+        new._cache.update(cache)
+        return new
 
     def is_terminal(self) -> bool:                          # go.py:205-206
         return self.consecutive_passes >= 2 or self.move_count >= 2 * self.board_size * self.board_size

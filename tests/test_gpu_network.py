@@ -119,13 +119,18 @@ EXACT = [("fused", dict(board_size=9, channels=192, num_blocks=12), 40), ("fused
          ("layers", dict(board_size=19, channels=256, num_blocks=3), 3), ("layers", dict(board_size=9, channels=256, num_blocks=2, value_hidden_dim=64), 9)]
 
 
+@pytest.mark.parametrize("small", ["small_variant", "256_row_kernel"])
 @pytest.mark.parametrize("path,kw,rows", EXACT, ids=[f"{p}-n{k['board_size']}_c{k['channels']}_b{k['num_blocks']}" for p, k, _ in EXACT])
-def test_bf16_exact_integer_network(path, kw, rows):
+def test_bf16_exact_integer_network(path, kw, rows, small, monkeypatch):
     """Networks with small-integer weights, binary inputs and squeeze-excite gates that saturate to exactly 0 or 1
     (tests/exactnet.py): no value is ever rounded, so every correct implementation gives the same logits bit for bit,
     whatever its tiling or summation order. The kernels must equal the emulation exactly on every row, including the
     ragged last board group; the value (a tanh) to 2e-6."""
     import exactnet
+    if small == "256_row_kernel":
+        if path != "fused" or kw["channels"] < 128:
+            pytest.skip("only the fused 128/192-channel towers have a second (96-row, low-latency) kernel to switch off")
+        monkeypatch.setenv("AZ_TOWER_SMALL", "0")       # few rows would otherwise all go through the 96-row variant
     net, x, lg_want, v_want = exactnet.find_exact_net(kw, path, rows)
     dev = torch.device("cuda:0")
     nn = net.to(dev).native("bf16", shared=False)
@@ -151,6 +156,25 @@ def test_bf16_rows_are_batch_invariant():
     assert torch.equal(lg_all[perm], lg_p) and torch.equal(v_all[perm], v_p)
     lg_1, v_1 = nn(f[7:8].contiguous())
     assert torch.equal(lg_all[7:8], lg_1) and torch.equal(v_all[7:8], v_1)
+
+
+def test_bf16_small_and_large_batches_agree_bitwise():
+    """Few rows run on the 96-row low-latency kernel (one board per workgroup), many on the 256-row kernel (three boards
+    per workgroup): a position's output is the same bits either way, whatever shares its workgroup."""
+    from alphazero_amd.model import AlphaZeroNet
+    import stubnets
+    for kw in (dict(board_size=9, channels=192, num_blocks=3), dict(board_size=9, channels=128, num_blocks=2, use_se=False),
+               dict(board_size=6, channels=192, num_blocks=2)):
+        net = _default_init(kw, seed=8)
+        n = kw["board_size"]
+        x = stubnets.synthetic_planes(1400, 21, n, seed=4)
+        dev = torch.device("cuda:0")
+        nn = net.to(dev).native("bf16", shared=False)
+        f = _to_nhwc_bf16(x).to(dev)
+        lg_all, v_all = nn(f)                                   # 1400 rows: 256-row kernel
+        for lo, hi in ((0, 1), (5, 46), (700, 1100), (1390, 1400)):   # 1, 41, 400, 10 rows: 96-row kernel
+            lg, v = nn(f[lo:hi].contiguous())
+            assert torch.equal(lg, lg_all[lo:hi]) and torch.equal(v, v_all[lo:hi]), (kw, lo, hi)
 
 
 def test_unsupported_bf16_shape_is_refused():
