@@ -464,6 +464,144 @@ __device__ __forceinline__ void gemm_conv_gw(f32x4 (&acc)[MI][NI], const uint4* 
     }
 }
 
+// gemm_conv_gw for a wave that owns ALL rows of the workgroup's image (row tiles 0..MI-1; the waves split channels only)
+// and must live in few registers: MI may be large (11 row tiles of a two-board image) next to two co-resident workgroups
+// per compute unit. Differences: the activation fragments sit in a ring of AR registers sets, fragment f+AR being read
+// right after the MFMAs that consumed fragment f (AR-1 groups of NI MFMAs cover each read); a tap's fragment offsets are
+// computed in place, one row tile at a time, just before the tile's first fragment of that tap is read, from one base
+// offset and the tap-validity bits of three row tiles packed per register.
+template <int MI, int NI, int WN, int NCOLS, int KPT, int DEPTH, int AR>
+__device__ __forceinline__ void gemm_conv_ring(f32x4 (&acc)[MI][NI], const uint4* __restrict__ wg, int ntaps, bool three, const char* act,
+                                               int in_stride, const char* zrow, const TileGeo& g) {
+    AZ_LANE_GEO(MI, NI, WN);
+    static_assert((KPT * MI) % AR == 0 && KPT % (DEPTH + 1) == 0, "the fragment rings must keep static indices across taps");
+    constexpr int NF = KPT * MI;          // fragments (groups of NI MFMAs) per tap
+    constexpr int NVM = (MI + 2) / 3;
+    const int nks = ntaps * KPT;
+    int vm[NVM];
+#pragma unroll
+    for (int i = 0; i < NVM; ++i) vm[i] = 0;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int row = mi * 16 + lr;
+        const int p = row - (int)((row * g.recip_np) >> 16) * g.np;
+        const int y = (p * g.recip_n) >> 16, x = p - y * g.n;
+        int m = 0;
+        if (row < g.vrows) {
+            if (three) {
+#pragma unroll
+                for (int tp = 0; tp < 9; ++tp) {
+                    const int yy = y + tp / 3 - 1, xx = x + tp % 3 - 1;
+                    if ((unsigned)yy < (unsigned)g.n && (unsigned)xx < (unsigned)g.n) m |= 1 << tp;
+                }
+            } else {
+                m = 1;
+            }
+        }
+        vm[mi / 3] |= m << (9 * (mi % 3));
+    }
+    const int roff0 = lr * in_stride + kq * 16;
+    const int zbase = (int)(zrow - act);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)wg, 0, nks * (NCOLS / 16) * 1024, 0x00020000);
+    const int wvoff = ((wn * NI) * 64 + lane) * 16;
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    auto wfrag = [&](int s, int ni) {
+        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff + ni * 1024, min(s, nks - 1) * (NCOLS / 16) * 1024, 0);
+        return __builtin_bit_cast(bf16x8, v);
+    };
+    auto tap_offset = [&](int tap, int mi) {
+        const int dy = three ? tap / 3 - 1 : 0, dx = three ? tap - (tap / 3) * 3 - 1 : 0;
+        const int shift = (dy * g.n + dx) * in_stride + mi * 16 * in_stride;
+        const int bit = tap < ntaps ? 1 << (tap + 9 * (mi % 3)) : 0;
+        const int reg = roff0 + shift;
+        return (vm[mi / 3] & bit) ? reg : zbase + (reg & 255);
+    };
+    int apc[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) apc[mi] = tap_offset(0, mi);
+    bf16x8 a[AR], b[DEPTH + 1][NI];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) b[d][ni] = wfrag(d, ni);
+    __syncthreads();   // the activation image is complete
+#pragma unroll
+    for (int f = 0; f < AR; ++f) a[f] = *(const bf16x8*)(act + apc[f % MI] + (f / MI) * 64);
+    int s = 0;
+    for (int tap = 0; tap < ntaps; ++tap) {
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            constexpr int NB = DEPTH + 1;
+            const int u = f / MI, mi = f - u * MI;
+            if (mi == 0) {
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) b[(u + DEPTH) % NB][ni] = wfrag(s + u + DEPTH, ni);
+            }
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[u % NB][ni], a[f % AR], acc[mi][ni], 0, 0, 0);
+            const int f2 = f + AR;
+            if (f2 < NF) {
+                a[f % AR] = *(const bf16x8*)(act + apc[f2 % MI] + (f2 / MI) * 64);
+            } else {   // the next tap's first fragments: their row tiles' offsets of this tap are no longer needed
+                const int m2 = f2 - NF;
+                apc[m2] = tap_offset(tap + 1, m2);
+                a[f % AR] = *(const bf16x8*)(act + apc[m2]);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, NI, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if (mi < NI) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            if (mi == MI - 1) __builtin_amdgcn_sched_barrier(0);
+        }
+        s += KPT;
+        // row tiles AR.. of the next tap: their offsets are first needed AR groups into it
+#pragma unroll
+        for (int mi = AR; mi < MI; ++mi) apc[mi] = tap_offset(tap + 1, mi);
+    }
+}
+
+// A short convolution (the stem: few k-steps) with the weight fragments read from the packed global image, one k-step
+// ahead, and nothing staged through LDS: `nksteps` k-steps of 32 input channels, `kpt` per tap. For kernels that have no
+// LDS to spare for weight staging buffers; its share of a tower's time is a few per cent, so it is not pipelined further.
+template <int MI, int NI, int WM, int WN, int NCOLS>
+__device__ __forceinline__ void gemm_taps_gw(f32x4 (&acc)[MI][NI], const uint4* __restrict__ wg, int nksteps, int kpt, int ntaps, bool three,
+                                             const char* act, int in_stride, const char* zrow, const TileGeo& g) {
+    AZ_LANE_GEO(MI, NI, WN);
+    int ry[MI], rx[MI], roff[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int row = row_base + mi * 16 + lr;
+        const int b = (row * g.recip_np) >> 16, p = row - b * g.np;
+        ry[mi] = (p * g.recip_n) >> 16;
+        rx[mi] = p - ry[mi] * g.n;
+        if (row >= g.vrows) ry[mi] = -64;   // fails every bounds check
+        roff[mi] = row * in_stride + kq * 16;
+    }
+    const int zoff = (int)(zrow - act) + kq * 16;
+    const uint4* wl = wg + (wn * NI) * 64 + lane;   // k-step s, tile ni: wl[(s * (NCOLS / 16) + ni) * 64]
+    bf16x8 b[2][NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) b[0][ni] = __builtin_bit_cast(bf16x8, wl[ni * 64]);
+    __syncthreads();   // the activation image is complete
+    int tap = 0, cc = 0;
+    for (int s = 0; s < nksteps; s += 2) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {   // two k-steps per trip keep the fragment ring's indices static
+            const int sn = min(s + h + 1, nksteps - 1);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) b[1 - h][ni] = __builtin_bit_cast(bf16x8, wl[((size_t)sn * (NCOLS / 16) + ni) * 64]);
+            int ap[MI];
+            frag_offsets<MI>(ap, ry, rx, roff, tap, cc, ntaps, three, g.n, in_stride, zoff);
+            if (++cc == kpt) { cc = 0; ++tap; }
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const bf16x8 a = *(const bf16x8*)(act + ap[mi]);
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[h][ni], a, acc[mi][ni], 0, 0, 0);
+            }
+        }
+    }
+}
+
 template <int MI, int NI>
 __device__ __forceinline__ void zero_acc(f32x4 (&acc)[MI][NI]) {
 #pragma unroll

@@ -30,6 +30,10 @@
 #include "az_net.h"
 #include "az_mfma_gemm.cuh"
 
+#ifndef AZ_RING
+#define AZ_RING 6   // activation-fragment ring of the two-workgroups-per-CU tower (gemm_conv_ring)
+#endif
+
 namespace az {
 int fail(int code, const std::string& msg);
 
@@ -124,7 +128,8 @@ __device__ __forceinline__ void store_act(const f32x4 (&acc)[MI][NI], const floa
 
 // Squeeze-excite gate of one block (model.py:9-22) applied to acc in place. The bf16 image of y is
 // in act; pooled/hidden/scale and the block's SE weights live in `scratch` (the idle weight buffers).
-template <int MI, int NI, int WM, int WN, int C, int STRIDE>
+// BLOB_GLOBAL: the block's squeeze-excite weights are read where they lie in global memory instead of being staged in LDS.
+template <int MI, int NI, int WM, int WN, int C, int STRIDE, bool BLOB_GLOBAL = false>
 __device__ __forceinline__ void se_gate(f32x4 (&acc)[MI][NI], const char* act, float* scratch, const uint4* __restrict__ blob, int se_vecs,
                                         int hid, int TB, int nb, const TileGeo& g
 #ifdef AZ_STAMP
@@ -137,9 +142,13 @@ __device__ __forceinline__ void se_gate(f32x4 (&acc)[MI][NI], const char* act, f
     float* pooled = scratch;                 // [TB][C]
     float* sc = pooled + TB * C;             // [TB][C], 16-byte aligned (C is a multiple of 4)
     float* hidden = sc + TB * C;             // [TB][hid]
-    char* sew = (char*)(hidden + TB * hid);  // this block's SE weights
-    sew += (16 - ((size_t)(sew - (char*)scratch) & 15)) & 15;
-    stage_tile<NW>(blob, sew, se_vecs, lane, wave);
+    const char* sew = (const char*)blob;     // this block's SE weights
+    if constexpr (!BLOB_GLOBAL) {
+        char* stage = (char*)(hidden + TB * hid);
+        stage += (16 - ((size_t)(stage - (char*)scratch) & 15)) & 15;
+        stage_tile<NW>(blob, stage, se_vecs, lane, wave);
+        sew = stage;
+    }
     const uint16_t* w1 = (const uint16_t*)sew;   // [hid][C] bf16
     const uint16_t* w2t = w1 + hid * C;          // [hid][C] bf16 (fc2 weight transposed)
     const float* b1 = (const float*)(w2t + hid * C);
@@ -199,6 +208,43 @@ __device__ __forceinline__ void se_gate(f32x4 (&acc)[MI][NI], const char* act, f
     }
     __syncthreads();
     STAMP(10);
+    if constexpr (BLOB_GLOBAL) {
+        // fc2 + sigmoid with the weights in global memory: a thread takes 8 consecutive channels of one board and reads
+        // a 16-byte vector per hidden unit, four of them in flight (the sums keep their order in j)
+        for (int i = t_; i < nb * (C / 8); i += NT) {
+            const int b = i / (C / 8), c8 = (i - b * (C / 8)) * 8;
+            float s[8];
+            {
+                const float4 x0 = *(const float4*)(b2 + c8), x1 = *(const float4*)(b2 + c8 + 4);
+                s[0] = x0.x; s[1] = x0.y; s[2] = x0.z; s[3] = x0.w; s[4] = x1.x; s[5] = x1.y; s[6] = x1.z; s[7] = x1.w;
+            }
+            const uint16_t* wr = w2t + c8;
+            int j = 0;
+            for (; j + 4 <= hid; j += 4) {
+                uint4 w[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) w[k] = *(const uint4*)(wr + (size_t)(j + k) * C);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float h = hidden[b * hid + j + k];
+                    s[0] = fmaf(bf16_lo(w[k].x), h, s[0]); s[1] = fmaf(bf16_hi(w[k].x), h, s[1]);
+                    s[2] = fmaf(bf16_lo(w[k].y), h, s[2]); s[3] = fmaf(bf16_hi(w[k].y), h, s[3]);
+                    s[4] = fmaf(bf16_lo(w[k].z), h, s[4]); s[5] = fmaf(bf16_hi(w[k].z), h, s[5]);
+                    s[6] = fmaf(bf16_lo(w[k].w), h, s[6]); s[7] = fmaf(bf16_hi(w[k].w), h, s[7]);
+                }
+            }
+            for (; j < hid; ++j) {
+                const uint4 w = *(const uint4*)(wr + (size_t)j * C);
+                const float h = hidden[b * hid + j];
+                s[0] = fmaf(bf16_lo(w.x), h, s[0]); s[1] = fmaf(bf16_hi(w.x), h, s[1]);
+                s[2] = fmaf(bf16_lo(w.y), h, s[2]); s[3] = fmaf(bf16_hi(w.y), h, s[3]);
+                s[4] = fmaf(bf16_lo(w.z), h, s[4]); s[5] = fmaf(bf16_hi(w.z), h, s[5]);
+                s[6] = fmaf(bf16_lo(w.w), h, s[6]); s[7] = fmaf(bf16_hi(w.w), h, s[7]);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sc[b * C + c8 + e] = 1.f / (1.f + __expf(-s[e]));
+        }
+    } else
     for (int i = t_; i < nb * C; i += NT) {   // fc2 + sigmoid
         const int b = i / C, ch = i - b * C;
         float s = b2[ch];
@@ -288,8 +334,11 @@ __device__ __forceinline__ void residual_store(const f32x4 (&acc)[MI][NI], const
 // ahead (gemm_conv_gw: no LDS staging, no barrier inside the loop).
 // ROWS: positions a workgroup holds (256: TB = 256/np boards; 96: the low-latency variant for small batches, one 9x9 board
 // per workgroup, so that a handful of positions spreads over as many compute units instead of queueing on one).
-template <int C, int WM, int WN, int NH, int GW = 0, int ROWS = 256>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_tower(TowerParams P) {
+// LEAN: no weight staging buffers and no staged squeeze-excite weights in LDS (stem and head read their weight fragments
+// from global memory too), which leaves room for OCC / ((WM*WN)/4) workgroups per compute unit: two 256-thread workgroups
+// of two boards each run their phases independently, so one's epilogues overlap the other's convolutions.
+template <int C, int WM, int WN, int NH, int GW = 0, int ROWS = 256, bool LEAN = false, int OCC = (WM * WN) / 4>
+__global__ __launch_bounds__(64 * WM * WN, OCC) void k_tower(TowerParams P) {
     constexpr int NW = WM * WN, NT = 64 * NW;
     constexpr int MI = ROWS / (WM * 16), NI = C / (WN * 16);
     constexpr int MIH = (ROWS + NW * 16 - 1) / (NW * 16), NIH = NH / 16;   // head: the waves split the row tiles; waves past ROWS compute zeros
@@ -339,7 +388,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_tower(TowerPara
         zero_acc<MI, NI>(acc);
         {
             const int kpt = P.cin_pad / 32, nks = (9 * kpt + 1) & ~1;
-            gemm_taps<MI, NI, WM, WN, C, false>(acc, P.w_stem, nks, kpt, 9, true, act, in_stride0, zrow, bbuf, g);
+            if constexpr (LEAN) gemm_taps_gw<MI, NI, WM, WN, C>(acc, P.w_stem, nks, kpt, 9, true, act, in_stride0, zrow, g);
+            else gemm_taps<MI, NI, WM, WN, C, false>(acc, P.w_stem, nks, kpt, 9, true, act, in_stride0, zrow, bbuf, g);
         }
         STAMP(0);
         store_act<MI, NI, WM, WN, STRIDE, true, true>(acc, P.b_stem, act, xres_wg);
@@ -351,14 +401,16 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_tower(TowerPara
         const size_t conv_vecs = (size_t)NKS * 32 * C * 2 / 16;
         for (int blk = 0; blk < P.blocks; ++blk) {
             zero_acc<MI, NI>(acc);
-            if constexpr (SAME && GW > 0) gemm_conv_gw<MI, NI, WM, WN, C, KPT, GW>(acc, P.w_tower + (size_t)(2 * blk) * conv_vecs, 9, true, act, STRIDE, zrow, g);
+            if constexpr (LEAN && WM == 1) gemm_conv_ring<MI, NI, WN, C, KPT, GW, AZ_RING>(acc, P.w_tower + (size_t)(2 * blk) * conv_vecs, 9, true, act, STRIDE, zrow, g);
+            else if constexpr (SAME && GW > 0) gemm_conv_gw<MI, NI, WM, WN, C, KPT, GW>(acc, P.w_tower + (size_t)(2 * blk) * conv_vecs, 9, true, act, STRIDE, zrow, g);
             else if constexpr (SAME) gemm_conv<MI, NI, WM, WN, C, KPT>(acc, P.w_tower + (size_t)(2 * blk) * conv_vecs, 9, true, act, STRIDE, zrow, bbuf, g);
             else gemm_taps<MI, NI, WM, WN, C, false>(acc, P.w_tower + (size_t)(2 * blk) * conv_vecs, NKS, KPT, 9, true, act, STRIDE, zrow, bbuf, g);
             STAMP(2);
             store_act<MI, NI, WM, WN, STRIDE, true, false>(acc, P.b_tower + (size_t)(2 * blk) * C, act, xres_wg);
             STAMP(3);
             zero_acc<MI, NI>(acc);
-            if constexpr (SAME && GW > 0) gemm_conv_gw<MI, NI, WM, WN, C, KPT, GW>(acc, P.w_tower + (size_t)(2 * blk + 1) * conv_vecs, 9, true, act, STRIDE, zrow, g);
+            if constexpr (LEAN && WM == 1) gemm_conv_ring<MI, NI, WN, C, KPT, GW, AZ_RING>(acc, P.w_tower + (size_t)(2 * blk + 1) * conv_vecs, 9, true, act, STRIDE, zrow, g);
+            else if constexpr (SAME && GW > 0) gemm_conv_gw<MI, NI, WM, WN, C, KPT, GW>(acc, P.w_tower + (size_t)(2 * blk + 1) * conv_vecs, 9, true, act, STRIDE, zrow, g);
             else if constexpr (SAME) gemm_conv<MI, NI, WM, WN, C, KPT>(acc, P.w_tower + (size_t)(2 * blk + 1) * conv_vecs, 9, true, act, STRIDE, zrow, bbuf, g);
             else gemm_taps<MI, NI, WM, WN, C, false>(acc, P.w_tower + (size_t)(2 * blk + 1) * conv_vecs, NKS, KPT, 9, true, act, STRIDE, zrow, bbuf, g);
             STAMP(2);
@@ -390,9 +442,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_tower(TowerPara
                 store_act<MI, NI, WM, WN, STRIDE, false, false>(acc, nullptr, act, xres_wg);   // bf16 image of y for the pooling
                 STAMP(7);
 #ifdef AZ_STAMP
-                se_gate<MI, NI, WM, WN, C, STRIDE>(acc, act, scratch, P.se_blob + (size_t)blk * P.se_vecs, P.se_vecs, P.hid, P.TB, nb, g, stamp_acc, stamp_last);
+                se_gate<MI, NI, WM, WN, C, STRIDE, LEAN>(acc, act, scratch, P.se_blob + (size_t)blk * P.se_vecs, P.se_vecs, P.hid, P.TB, nb, g, stamp_acc, stamp_last);
 #else
-                se_gate<MI, NI, WM, WN, C, STRIDE>(acc, act, scratch, P.se_blob + (size_t)blk * P.se_vecs, P.se_vecs, P.hid, P.TB, nb, g);
+                se_gate<MI, NI, WM, WN, C, STRIDE, LEAN>(acc, act, scratch, P.se_blob + (size_t)blk * P.se_vecs, P.se_vecs, P.hid, P.TB, nb, g);
 #endif
             }
             STAMP(4);
@@ -405,7 +457,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_tower(TowerPara
             f32x4 hacc[MIH][NIH];
             zero_acc<MIH, NIH>(hacc);
             constexpr int NKH = (KPT + 1) & ~1;
-            if constexpr (SAME) gemm_conv<MIH, NIH, NW, 1, NH, KPT>(hacc, P.w_head, 1, false, act, STRIDE, zrow, bbuf, g);
+            if constexpr (LEAN && SAME) gemm_conv_gw<MIH, NIH, NW, 1, NH, KPT, 1>(hacc, P.w_head, 1, false, act, STRIDE, zrow, g);
+            else if constexpr (SAME) gemm_conv<MIH, NIH, NW, 1, NH, KPT>(hacc, P.w_head, 1, false, act, STRIDE, zrow, bbuf, g);
             else gemm_taps<MIH, NIH, NW, 1, NH, false>(hacc, P.w_head, NKH, KPT, 1, false, act, STRIDE, zrow, bbuf, g);
             // relu(acc + bias) -> LDS as [row][2q] bf16, then one coalesced copy: the workgroup's slice of hq is contiguous
             AZ_LANE_GEO(MIH, NIH, 1);
@@ -660,6 +713,7 @@ struct MfmaNet {
     int cus = 256;                // compute units of the device
     std::vector<void*> retired;   // scratch buffers that were replaced by larger ones: launches already enqueued may still use
                                   // them, so they are only freed with the network (sizes grow geometrically: bounded waste)
+    int TB_duo = 0;               // boards per workgroup of the two-workgroups-per-CU variant (176 rows, 256 threads; 0: none)
     int TB_small = 0;             // boards per workgroup of the 96-row low-latency variant (0: this shape has none)
     int split = 0;                // 0: 4x2 waves, weights through LDS; 1: 2x4 waves, weight fragments from global memory (C = 192)
     LayerNet* layers = nullptr;   // set instead of the fused tower's weights when the shape needs the layer-by-layer path
@@ -687,6 +741,13 @@ static bool fused_supported(const az_net_config& c) {
 bool mfma_supported(const az_net_config& c) { return (fused_supported(c) || layers_supported(c)) && c.value_hidden >= 1; }
 bool mfma_is_fused(const MfmaNet* m) { return m->layers == nullptr; }
 
+// Residual scratch for `workgroups` resident workgroups of the 256-row kernel; the two-per-CU variant runs twice as many
+// workgroups of 17 x 256 vectors each out of the same buffer.
+static size_t xres_bytes(int workgroups, int C, bool duo) {
+    const size_t per = (size_t)256 * C * 2, per_duo = (size_t)2 * 17 * 256 * 16;
+    return (size_t)workgroups * std::max(per, duo ? per_duo : (size_t)0);
+}
+
 static size_t se_blob_bytes(int C, int hid) {  // per block: w1, w2^T (bf16), b1, b2 (f32), padded to 1 KiB
     const size_t raw = (size_t)2 * hid * C * 2 + (size_t)(hid + C) * 4;
     return (raw + 1023) / 1024 * 1024;
@@ -695,10 +756,10 @@ static size_t se_blob_bytes(int C, int hid) {  // per block: w1, w2^T (bf16), b1
 // LDS: activations, zero row, then a region shared by the two weight staging buffers and the
 // squeeze-excite scratch (pooled [TB][C], hidden [TB][hid], scale [TB][C],
 // the block's SE weights).
-static size_t tower_lds_bytes(int C, int NH, int TB, int hid, int rows = 256) {
+static size_t tower_lds_bytes(int C, int NH, int TB, int hid, int rows = 256, bool lean = false) {
     const size_t stride = 2 * C + 32;
-    const size_t tile = (size_t)64 * std::max(C, NH) * 2;
-    const size_t se = ((size_t)2 * TB * C + (size_t)TB * hid) * 4 + 16 + se_blob_bytes(C, hid);
+    const size_t tile = lean ? 0 : (size_t)64 * std::max(C, NH) * 2;
+    const size_t se = ((size_t)2 * TB * C + (size_t)TB * hid) * 4 + 16 + (lean ? 0 : se_blob_bytes(C, hid));
     const size_t zbytes = ((256 + 2 * (size_t)C + 16 + 127) / 128) * 128;
     return (((size_t)rows * stride + 255) / 256) * 256 + zbytes + std::max(2 * tile, se);
 }
@@ -720,6 +781,10 @@ int mfma_create(const az_net_config& c, const NetLayout& L, const float* Pm, Mfm
     // form, boards of at most 96 points; AZ_TOWER_SMALL=0 switches it off
     m->TB_small = (fused && m->split == 1 && (C == 128 || C == 192) && np <= 96) ? 96 / np : 0;
     if (const char* sm = getenv("AZ_TOWER_SMALL")) if (atoi(sm) == 0) m->TB_small = 0;
+    // two 256-thread workgroups of two boards per compute unit (192 channels, global-weights form)
+    // where whole boards fill at least 90 % of its 176 rows (9x9: 162, 5x5: 175); AZ_TOWER_DUO=0 switches it off
+    m->TB_duo = (fused && m->split == 1 && C == 192 && np <= 88 && (176 / np) * np * 10 >= 176 * 9) ? 176 / np : 0;
+    if (const char* du = getenv("AZ_TOWER_DUO")) if (atoi(du) == 0) m->TB_duo = 0;
     const int tiles_per_wave = C / 64;              // 2x4 waves: C/4 channels each
     const int slab_tiles = (m->split == 1 && (tiles_per_wave & 1)) ? tiles_per_wave : 0;   // channel tiles per wave when that count is odd
     if (fused && tower_lds_bytes(C, m->NH, m->TB, c.se_hidden) > 160 * 1024) { delete m; return fail(AZ_ERR_ARG, "bf16 MFMA path: LDS budget exceeded"); }
@@ -860,6 +925,9 @@ int mfma_create(const az_net_config& c, const NetLayout& L, const float* Pm, Mfm
             if (e == hipSuccess && m->TB_small)
                 e = hipFuncSetAttribute((const void*)k_tower<192, 2, 4, 96, 2, 96>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)tower_lds_bytes(C, m->NH, m->TB_small, c.se_hidden, 96));
+            if (e == hipSuccess && m->TB_duo)
+                e = hipFuncSetAttribute((const void*)k_tower<192, 1, 4, 96, 2, 176, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)tower_lds_bytes(C, m->NH, m->TB_duo, c.se_hidden, 176, true));
             break;
     }
     if (e != hipSuccess) { mfma_destroy(m); return fail(AZ_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); }
@@ -873,7 +941,7 @@ int mfma_create(const az_net_config& c, const NetLayout& L, const float* Pm, Mfm
         if (hipGetDeviceProperties(&prop, c.device) != hipSuccess) { mfma_destroy(m); return fail(AZ_ERR_HIP, "hipGetDeviceProperties"); }
         m->max_grid = std::max(1, prop.multiProcessorCount);
         m->cus = m->max_grid;
-        if (hipMalloc((void**)&m->xres, (size_t)m->max_grid * 256 * (size_t)C * 2) != hipSuccess) { mfma_destroy(m); return fail(AZ_ERR_HIP, "hipMalloc (residual scratch)"); }
+        if (hipMalloc((void**)&m->xres, xres_bytes(m->max_grid, C, m->TB_duo > 0)) != hipSuccess) { mfma_destroy(m); return fail(AZ_ERR_HIP, "hipMalloc (residual scratch)"); }
     } else {   // layer path: head activations (and value-tail shares) of one chunk, sized once
         int rcr = mfma_reserve(m, layers_chunk_boards(m->layers));
         if (rcr != AZ_OK) { mfma_destroy(m); return rcr; }
@@ -929,7 +997,7 @@ int mfma_set_grid_limit(MfmaNet* m, int workgroups) {
     if (workgroups == m->max_grid) return AZ_OK;
     if (hipSetDevice(m->cfg.device) != hipSuccess) return fail(AZ_ERR_HIP, "hipSetDevice");
     uint4* x = nullptr;
-    if (hipMalloc((void**)&x, (size_t)workgroups * 256 * (size_t)m->cfg.channels * 2) != hipSuccess) return fail(AZ_ERR_HIP, "hipMalloc (residual scratch)");
+    if (hipMalloc((void**)&x, xres_bytes(workgroups, m->cfg.channels, m->TB_duo > 0)) != hipSuccess) return fail(AZ_ERR_HIP, "hipMalloc (residual scratch)");
     if (m->xres) m->retired.push_back(m->xres);
     m->xres = x;
     m->max_grid = workgroups;
@@ -1045,6 +1113,7 @@ static int prof_begin(MfmaNet* m, long long rows, hipStream_t st, std::pair<hipE
 // Fused tower + tails with the given scratch (head activations for `rows` rows, residual stream for `grid_cap` workgroups).
 static int fused_forward(MfmaNet* m, const void* feat, int rows, const int* rows_dev, float* logits, float* values, hipStream_t st,
                          uint16_t* hq, uint4* xres, int grid_cap, bool timed) {
+    const bool static_scratch_call = !timed;   // the static scratch array is laid out for the 256-row kernel
     const az_net_config& c = m->cfg;
     const int C = c.channels;
     TowerParams P = m->P;
@@ -1057,11 +1126,12 @@ static int fused_forward(MfmaNet* m, const void* feat, int rows, const int* rows
     // compute units instead of queueing three boards deep on a few. It wins while its workgroups fit two rounds
     // (a round takes about 0.4 of a 256-row round); `rows` is the upper bound when the count lives on the device.
     const bool small = m->TB_small > 0 && (rows + m->TB_small - 1) / m->TB_small <= 2 * m->cus;
-    const int TB = small ? m->TB_small : m->TB;
+    const bool duo = !small && m->TB_duo > 0 && !static_scratch_call;
+    const int TB = small ? m->TB_small : duo ? m->TB_duo : m->TB;
     P.TB = TB;
     P.items = (rows + TB - 1) / TB;
     P.rows_dev = rows_dev;
-    const int grid = std::min(P.items, grid_cap);
+    const int grid = std::min(P.items, duo ? 2 * grid_cap : grid_cap);
 #ifdef AZ_STAMP
     static unsigned long long* stamp_dev = nullptr;
     static int stamp_grid = 0;
@@ -1072,7 +1142,7 @@ static int fused_forward(MfmaNet* m, const void* feat, int rows, const int* rows
     }
     P.stamps = stamp_dev;
 #endif
-    const size_t lds = tower_lds_bytes(C, m->NH, TB, c.se_hidden, small ? 96 : 256);
+    const size_t lds = tower_lds_bytes(C, m->NH, TB, c.se_hidden, small ? 96 : duo ? 176 : 256, duo);
     std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
     if (timed) {
         int rcp = prof_begin(m, rows_dev ? 0 : rows, st, &ev);   // indirect launches: the caller knows the row total
@@ -1091,6 +1161,7 @@ static int fused_forward(MfmaNet* m, const void* feat, int rows, const int* rows
             break;
         case 192:
             if (small) hipLaunchKernelGGL((k_tower<192, 2, 4, 96, 2, 96>), dim3(grid), dim3(512), lds, st, P);
+            else if (duo) hipLaunchKernelGGL((k_tower<192, 1, 4, 96, 2, 176, true, 2>), dim3(grid), dim3(256), lds, st, P);
             else if (m->split == 1) hipLaunchKernelGGL((k_tower<192, 2, 4, 96, 2>), dim3(grid), dim3(512), lds, st, P);
             else hipLaunchKernelGGL((k_tower<192, 4, 2, 96>), dim3(grid), dim3(512), lds, st, P);
             break;
@@ -1102,16 +1173,17 @@ static int fused_forward(MfmaNet* m, const void* feat, int rows, const int* rows
     if (err != hipSuccess) return fail(AZ_ERR_HIP, std::string("bf16 forward: ") + hipGetErrorString(err));
 #ifdef AZ_STAMP
     {   // diagnostic build: print where a workgroup's cycles go (mean over workgroups)
-        std::vector<unsigned long long> hst((size_t)grid * 8 * 16);   // 8 waves per workgroup in every instantiation
+        const int nwv = duo ? 4 : 8;   // waves per workgroup
+        std::vector<unsigned long long> hst((size_t)grid * nwv * 16);
         (void)hipDeviceSynchronize();
         (void)hipMemcpy(hst.data(), P.stamps, hst.size() * 8, hipMemcpyDeviceToHost);
         double sum[16] = {0}, conv_w[8] = {0};
         for (int g = 0; g < grid; ++g) {
-            for (int i = 0; i < 16; ++i) sum[i] += (double)hst[(size_t)g * 8 * 16 + i];          // wave 0's view
-            for (int w = 0; w < 8; ++w) conv_w[w] += (double)hst[((size_t)g * 8 + w) * 16 + 2];
+            for (int i = 0; i < 16; ++i) sum[i] += (double)hst[(size_t)g * nwv * 16 + i];          // wave 0's view
+            for (int w = 0; w < nwv; ++w) conv_w[w] += (double)hst[((size_t)g * nwv + w) * 16 + 2];
         }
         fprintf(stderr, "[AZ_STAMP] conv gemm cycles per wave:");
-        for (int w = 0; w < 8; ++w) fprintf(stderr, " %.0f", conv_w[w] / grid);
+        for (int w = 0; w < nwv; ++w) fprintf(stderr, " %.0f", conv_w[w] / grid);
         fprintf(stderr, "\n");
         const char* nm[16] = {"load+stem gemm", "stem epilogue", "conv gemm (2/blk)", "conv1 epilogue", "SE scale", "residual epilogue", "head gemm+store",
                               "resv issue+bias+y image", "SE pooling", "SE wait+sync", "SE fc1", "SE fc2", "-", "-", "-", "-"};

@@ -115,11 +115,12 @@ def test_bf16_path_golden_weights(name):
 EXACT = [("fused", dict(board_size=9, channels=192, num_blocks=12), 40), ("fused", dict(board_size=9, channels=128, num_blocks=3), 40),
          ("fused", dict(board_size=9, channels=64, num_blocks=4, use_se=False), 41), ("fused", dict(board_size=5, channels=32, num_blocks=2, value_hidden_dim=64), 23),
          ("fused", dict(board_size=7, channels=128, num_blocks=3, history_len=4), 17), ("fused", dict(board_size=6, channels=192, num_blocks=2), 15),
+         ("fused", dict(board_size=5, channels=192, num_blocks=2, value_hidden_dim=64), 30),
          ("layers", dict(board_size=13, channels=64, num_blocks=2), 5), ("layers", dict(board_size=19, channels=128, num_blocks=2), 4),
          ("layers", dict(board_size=19, channels=256, num_blocks=3), 3), ("layers", dict(board_size=9, channels=256, num_blocks=2, value_hidden_dim=64), 9)]
 
 
-@pytest.mark.parametrize("small", ["small_variant", "256_row_kernel"])
+@pytest.mark.parametrize("small", ["small_variant", "two_per_cu_kernel", "256_row_kernel"])
 @pytest.mark.parametrize("path,kw,rows", EXACT, ids=[f"{p}-n{k['board_size']}_c{k['channels']}_b{k['num_blocks']}" for p, k, _ in EXACT])
 def test_bf16_exact_integer_network(path, kw, rows, small, monkeypatch):
     """Networks with small-integer weights, binary inputs and squeeze-excite gates that saturate to exactly 0 or 1
@@ -127,10 +128,14 @@ def test_bf16_exact_integer_network(path, kw, rows, small, monkeypatch):
     whatever its tiling or summation order. The kernels must equal the emulation exactly on every row, including the
     ragged last board group; the value (a tanh) to 2e-6."""
     import exactnet
-    if small == "256_row_kernel":
+    if small != "small_variant":
         if path != "fused" or kw["channels"] < 128:
             pytest.skip("only the fused 128/192-channel towers have a second (96-row, low-latency) kernel to switch off")
         monkeypatch.setenv("AZ_TOWER_SMALL", "0")       # few rows would otherwise all go through the 96-row variant
+        if small == "256_row_kernel":
+            monkeypatch.setenv("AZ_TOWER_DUO", "0")     # 192 channels on 9x9 / 5x5 otherwise run two 176-row workgroups per CU
+        elif kw["channels"] != 192 or kw["board_size"] not in (5, 9):
+            pytest.skip("the two-workgroups-per-CU kernel serves 192 channels on 9x9 and 5x5")
     net, x, lg_want, v_want = exactnet.find_exact_net(kw, path, rows)
     dev = torch.device("cuda:0")
     nn = net.to(dev).native("bf16", shared=False)
@@ -159,8 +164,9 @@ def test_bf16_rows_are_batch_invariant():
 
 
 def test_bf16_small_and_large_batches_agree_bitwise():
-    """Few rows run on the 96-row low-latency kernel (one board per workgroup), many on the 256-row kernel (three boards
-    per workgroup): a position's output is the same bits either way, whatever shares its workgroup."""
+    """Few rows run on the 96-row low-latency kernel (one board per workgroup), many on the 176-row kernel (192 channels on
+    9x9: two boards per workgroup, two workgroups per compute unit) or the 256-row kernel (three boards per workgroup):
+    a position's output is the same bits whichever kernel computes it and whatever shares its workgroup."""
     from alphazero_amd.model import AlphaZeroNet
     import stubnets
     for kw in (dict(board_size=9, channels=192, num_blocks=3), dict(board_size=9, channels=128, num_blocks=2, use_se=False),
@@ -171,7 +177,16 @@ def test_bf16_small_and_large_batches_agree_bitwise():
         dev = torch.device("cuda:0")
         nn = net.to(dev).native("bf16", shared=False)
         f = _to_nhwc_bf16(x).to(dev)
-        lg_all, v_all = nn(f)                                   # 1400 rows: 256-row kernel
+        lg_all, v_all = nn(f)                                   # 1400 rows: 176-row or 256-row kernel
+        if kw["channels"] == 192 and n == 9:
+            import os
+            os.environ["AZ_TOWER_DUO"] = "0"
+            try:
+                nn256 = net.native("bf16", shared=False)        # the 256-row kernel for the same weights
+                lg_256, v_256 = nn256(f)
+            finally:
+                del os.environ["AZ_TOWER_DUO"]
+            assert torch.equal(lg_256, lg_all) and torch.equal(v_256, v_all)
         for lo, hi in ((0, 1), (5, 46), (700, 1100), (1390, 1400)):   # 1, 41, 400, 10 rows: 96-row kernel
             lg, v = nn(f[lo:hi].contiguous())
             assert torch.equal(lg, lg_all[lo:hi]) and torch.equal(v, v_all[lo:hi]), (kw, lo, hi)
