@@ -349,8 +349,8 @@ def main():
                      "layer-by-layer network (k_conv3_slab + gate / residual / tail kernels), timed as one sequence", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS,
                      "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
                      "traffic": traffic if headline else None,
-                     "traffic_note": f"bytes per launch on the L2's memory side (Infinity Cache hits included), PMC passes in profiles/{traffic_src}; "
-                                     "mostly the bf16 residual stream parked per workgroup between the two convolutions of a block",
+                     "traffic_note": (f"bytes per launch on the L2's memory side (Infinity Cache hits included), PMC passes in profiles/{traffic_src}; "
+                                      "mostly the bf16 residual stream parked per workgroup between the two convolutions of a block") if headline else None,
                      "launches": int(launches), "avg_launch_ms": round(per_launch_ms, 4),
                      "avg_launch_ms_start_to_end": round(tower_ms_sum / max(1, launches), 4),
                      "achieved_start_to_end": round((tower_rows * fl_pos) / (tower_ms_sum * 1e-3) / 1e12, 1) if tower_ms_sum > 0 else 0.0,
