@@ -31,7 +31,7 @@
 #include "az_mfma_gemm.cuh"
 
 #ifndef AZ_RING
-#define AZ_RING 6   // activation-fragment ring of the two-workgroups-per-CU tower (gemm_conv_ring)
+#define AZ_RING 6        // activation-fragment ring of the two-workgroups-per-CU tower (gemm_conv_ring)
 #endif
 
 namespace az {
@@ -128,7 +128,11 @@ __device__ __forceinline__ void store_act(const f32x4 (&acc)[MI][NI], const floa
 
 // Squeeze-excite gate of one block (model.py:9-22) applied to acc in place. The bf16 image of y is
 // in act; pooled/hidden/scale and the block's SE weights live in `scratch` (the idle weight buffers).
-// BLOB_GLOBAL: the block's squeeze-excite weights are read where they lie in global memory instead of being staged in LDS.
+// BLOB_GLOBAL: the block's squeeze-excite weights are read where they lie in global memory instead of being staged in LDS
+// (for workgroups whose LDS has no room for a staging area). Staging them into the activation image once the pooling
+// has read it - the image is dead from then until the residual store - was measured 1-2 % slower than reading them from
+// global memory: the extra barrier and the exposed load latency cost more than the faster fc2 gains while the compute
+// unit's other workgroup keeps the matrix pipes busy anyway.
 template <int MI, int NI, int WM, int WN, int C, int STRIDE, bool BLOB_GLOBAL = false>
 __device__ __forceinline__ void se_gate(f32x4 (&acc)[MI][NI], const char* act, float* scratch, const uint4* __restrict__ blob, int se_vecs,
                                         int hid, int TB, int nb, const TileGeo& g
@@ -357,8 +361,13 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void k_tower(TowerParams P) {
 #ifdef AZ_STAMP
     unsigned long long stamp_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_last;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
+    stamp_acc[12] = stamp_last;   // absolute start
 #endif
     for (int i = tid; i < ZBYTES / 4; i += NT) ((uint32_t*)zrow)[i] = 0;
+    // Two workgroups per compute unit: the issue arbiter prefers the older wave of a SIMD, so in a launch that fills the
+    // chip exactly the workgroup that arrived first on a compute unit runs ahead (6.3 M against 8.1 M cycles for the same four
+    // items). Alternating s_setprio between the two (by convolution parity, by clock parity, younger first) evens that out
+    // and shortens such a launch by 1-3 %, but costs 3-4 % of the throughput with several launches in flight: left to age.
     TileGeo g;
     g.row0 = 0; g.n = P.n; g.np = P.np; g.recip_np = P.recip_np; g.recip_n = P.recip_n;
     const int rows = P.rows_dev ? min(*P.rows_dev, P.rows) : P.rows;
@@ -490,6 +499,13 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void k_tower(TowerParams P) {
         STAMP(6);
     }  // item loop
 #ifdef AZ_STAMP
+    stamp_acc[13] = stamp_last;   // absolute end
+    {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        stamp_acc[14] = hw; stamp_acc[15] = xcc;
+    }
     if ((tid & 63) == 0 && P.stamps)   // one record per wave
         for (int i = 0; i < 16; ++i) P.stamps[((size_t)blockIdx.x * NW + (tid >> 6)) * 16 + i] = stamp_acc[i];
 #endif
@@ -1190,6 +1206,31 @@ static int fused_forward(MfmaNet* m, const void* feat, int rows, const int* rows
         double tot = 0; for (int i = 0; i < 12; ++i) tot += sum[i];
         fprintf(stderr, "[AZ_STAMP] rows=%d grid=%d mean cycles/WG=%.0f\n", rows, grid, tot / grid);
         for (int i = 0; i < 12; ++i) fprintf(stderr, "  %-20s %10.0f  %5.1f%%\n", nm[i], sum[i] / grid, 100.0 * sum[i] / tot);
+        {   // spread over workgroups: busy cycles, start and end relative to the first start
+            unsigned long long t0 = ~0ull, t1 = 0, smax = 0;
+            double bmin = 1e30, bmax = 0;
+            for (int g = 0; g < grid; ++g) {
+                const unsigned long long* r = &hst[(size_t)g * nwv * 16];
+                double b = 0; for (int i = 0; i < 12; ++i) b += (double)r[i];
+                bmin = std::min(bmin, b); bmax = std::max(bmax, b);
+                t0 = std::min(t0, r[12]); t1 = std::max(t1, r[13]);
+            }
+            for (int g = 0; g < grid; ++g) smax = std::max(smax, hst[(size_t)g * nwv * 16 + 12] - t0);
+            fprintf(stderr, "[AZ_STAMP] busy cycles/WG min %.0f max %.0f; first start to last end %llu; latest start +%llu\n", bmin, bmax, t1 - t0, smax);
+            int hist[10] = {0};
+            for (int g = 0; g < grid; ++g) { const unsigned long long e = hst[(size_t)g * nwv * 16 + 13] - t0; hist[std::min(9, (int)(e * 10 / (t1 - t0 + 1)))]++; }
+            if (const char* dump = getenv("AZ_STAMP_DUMP")) {   // raw per-wave records: wg wave hw_id xcc_id start end busy conv
+                FILE* f = fopen(dump, "w");
+                for (int g = 0; f && g < grid; ++g)
+                    for (int w = 0; w < nwv; ++w) {
+                        const unsigned long long* r = &hst[((size_t)g * nwv + w) * 16];
+                        double b = 0; for (int i = 0; i < 12; ++i) b += (double)r[i];
+                        fprintf(f, "%d %d %llu %llu %llu %llu %.0f %llu\n", g, w, r[14], r[15], r[12], r[13], b, r[2]);
+                    }
+                if (f) fclose(f);
+            }
+            fprintf(stderr, "[AZ_STAMP] end-time deciles:"); for (int i = 0; i < 10; ++i) fprintf(stderr, " %d", hist[i]); fprintf(stderr, "\n");
+        }
     }
 #endif
     return AZ_OK;
