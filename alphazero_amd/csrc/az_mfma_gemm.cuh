@@ -467,41 +467,20 @@ __device__ __forceinline__ void gemm_conv_gw(f32x4 (&acc)[MI][NI], const uint4* 
 // gemm_conv_gw for a wave that owns ALL rows of the workgroup's image (row tiles 0..MI-1; the waves split channels only)
 // and must live in few registers: MI may be large (11 row tiles of a two-board image) next to two co-resident workgroups
 // per compute unit. Differences: the activation fragments sit in a ring of AR registers sets, fragment f+AR being read
-// right after the MFMAs that consumed fragment f (AR-1 groups of NI MFMAs cover each read); a tap's fragment offsets are
-// computed in place, one row tile at a time, just before the tile's first fragment of that tap is read, from one base
-// offset and the tap-validity bits of three row tiles packed per register.
+// right after the MFMAs that consumed fragment f (AR-1 groups of NI MFMAs cover each read); where a row tile's fragments
+// of a tap start comes from a table in LDS, `taptab[tap][row]` (build_tap_table: offset / 16 of the tap's source row, or
+// of the bank-preserving spot in the zero region when the tap falls off the board), read into the tile's offset register
+// as soon as its last fragment of the previous tap has been requested - one 2-byte LDS read and one shift-add per row
+// tile and tap instead of a bounds test, two address computations and a select.
 template <int MI, int NI, int WN, int NCOLS, int KPT, int DEPTH, int AR>
-__device__ __forceinline__ void gemm_conv_ring(f32x4 (&acc)[MI][NI], const uint4* __restrict__ wg, int ntaps, bool three, const char* act,
-                                               int in_stride, const char* zrow, const TileGeo& g) {
+__device__ __forceinline__ void gemm_conv_ring(f32x4 (&acc)[MI][NI], const uint4* __restrict__ wg, int ntaps, const char* act,
+                                               const uint16_t* taptab) {
     AZ_LANE_GEO(MI, NI, WN);
-    static_assert((KPT * MI) % AR == 0 && KPT % (DEPTH + 1) == 0, "the fragment rings must keep static indices across taps");
+    static_assert((KPT * MI) % AR == 0 && KPT % (DEPTH + 1) == 0 && AR < MI, "the fragment rings must keep static indices across taps");
     constexpr int NF = KPT * MI;          // fragments (groups of NI MFMAs) per tap
-    constexpr int NVM = (MI + 2) / 3;
+    constexpr int ROWS = MI * 16;
     const int nks = ntaps * KPT;
-    int vm[NVM];
-#pragma unroll
-    for (int i = 0; i < NVM; ++i) vm[i] = 0;
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-        const int row = mi * 16 + lr;
-        const int p = row - (int)((row * g.recip_np) >> 16) * g.np;
-        const int y = (p * g.recip_n) >> 16, x = p - y * g.n;
-        int m = 0;
-        if (row < g.vrows) {
-            if (three) {
-#pragma unroll
-                for (int tp = 0; tp < 9; ++tp) {
-                    const int yy = y + tp / 3 - 1, xx = x + tp % 3 - 1;
-                    if ((unsigned)yy < (unsigned)g.n && (unsigned)xx < (unsigned)g.n) m |= 1 << tp;
-                }
-            } else {
-                m = 1;
-            }
-        }
-        vm[mi / 3] |= m << (9 * (mi % 3));
-    }
-    const int roff0 = lr * in_stride + kq * 16;
-    const int zbase = (int)(zrow - act);
+    const int kq16 = kq * 16;
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)wg, 0, nks * (NCOLS / 16) * 1024, 0x00020000);
     const int wvoff = ((wn * NI) * 64 + lane) * 16;
     typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
@@ -509,16 +488,11 @@ __device__ __forceinline__ void gemm_conv_ring(f32x4 (&acc)[MI][NI], const uint4
         const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff + ni * 1024, min(s, nks - 1) * (NCOLS / 16) * 1024, 0);
         return __builtin_bit_cast(bf16x8, v);
     };
-    auto tap_offset = [&](int tap, int mi) {
-        const int dy = three ? tap / 3 - 1 : 0, dx = three ? tap - (tap / 3) * 3 - 1 : 0;
-        const int shift = (dy * g.n + dx) * in_stride + mi * 16 * in_stride;
-        const int bit = tap < ntaps ? 1 << (tap + 9 * (mi % 3)) : 0;
-        const int reg = roff0 + shift;
-        return (vm[mi / 3] & bit) ? reg : zbase + (reg & 255);
-    };
+    // apc[mi]: before a tap's first fragment of row tile mi is requested, the table entry; from then on the byte offset
     int apc[MI];
+    const uint16_t* tb = taptab + lr;
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) apc[mi] = tap_offset(0, mi);
+    for (int mi = 0; mi < MI; ++mi) apc[mi] = tb[mi * 16];
     bf16x8 a[AR], b[DEPTH + 1][NI];
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d)
@@ -526,9 +500,13 @@ __device__ __forceinline__ void gemm_conv_ring(f32x4 (&acc)[MI][NI], const uint4
         for (int ni = 0; ni < NI; ++ni) b[d][ni] = wfrag(d, ni);
     __syncthreads();   // the activation image is complete
 #pragma unroll
-    for (int f = 0; f < AR; ++f) a[f] = *(const bf16x8*)(act + apc[f % MI] + (f / MI) * 64);
+    for (int f = 0; f < AR; ++f) {
+        apc[f] = (apc[f] << 4) + kq16;
+        a[f] = *(const bf16x8*)(act + apc[f]);
+    }
     int s = 0;
     for (int tap = 0; tap < ntaps; ++tap) {
+        tb += (tap + 1 < ntaps) ? ROWS : 0;   // the next tap's table row (the last tap reads its own again: harmless)
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
             constexpr int NB = DEPTH + 1;
@@ -540,22 +518,40 @@ __device__ __forceinline__ void gemm_conv_ring(f32x4 (&acc)[MI][NI], const uint4
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[u % NB][ni], a[f % AR], acc[mi][ni], 0, 0, 0);
             const int f2 = f + AR;
+            bool table_read = false;
             if (f2 < NF) {
-                a[f % AR] = *(const bf16x8*)(act + apc[f2 % MI] + (f2 / MI) * 64);
-            } else {   // the next tap's first fragments: their row tiles' offsets of this tap are no longer needed
+                const int m2 = f2 % MI, u2 = f2 / MI;
+                if (u2 == 0) apc[m2] = (apc[m2] << 4) + kq16;   // row tiles AR..: first fragment of this tap
+                a[f % AR] = *(const bf16x8*)(act + apc[m2] + u2 * 64);
+                if (u2 == KPT - 1) { apc[m2] = tb[m2 * 16]; table_read = true; }   // the tile's last fragment of this tap
+            } else {   // the next tap's first fragments (row tiles 0..AR-1)
                 const int m2 = f2 - NF;
-                apc[m2] = tap_offset(tap + 1, m2);
+                apc[m2] = (apc[m2] << 4) + kq16;
                 a[f % AR] = *(const bf16x8*)(act + apc[m2]);
             }
             __builtin_amdgcn_sched_group_barrier(0x008, NI, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if (table_read) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             if (mi < NI) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
             if (mi == MI - 1) __builtin_amdgcn_sched_barrier(0);
         }
         s += KPT;
-        // row tiles AR.. of the next tap: their offsets are first needed AR groups into it
-#pragma unroll
-        for (int mi = AR; mi < MI; ++mi) apc[mi] = tap_offset(tap + 1, mi);
+    }
+}
+
+// The table gemm_conv_ring reads: for every tap of a 3x3 convolution and every row of a workgroup's activation image
+// (`rows` rows of `stride` bytes, the first g.vrows of them valid; zbase = byte offset of the zero region, a multiple of
+// 256), where the tap's source row starts, in units of 16 bytes. A tap that falls off the board (or a row past the valid
+// ones) points into the zero region at the spot with the same low 8 address bits, so that the fragment reads keep their
+// LDS bank pattern. All threads of the workgroup take part; the caller synchronises before the first use.
+__device__ __forceinline__ void build_tap_table(uint16_t* taptab, int rows, int stride, int zbase, const TileGeo& g, int tid, int nthreads) {
+    for (int i = tid; i < 9 * rows; i += nthreads) {
+        const int tap = i / rows, row = i - tap * rows;
+        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+        const int p = row - (int)((row * g.recip_np) >> 16) * g.np;
+        const int y = (p * g.recip_n) >> 16, x = p - y * g.n;
+        const int src = (row + dy * g.n + dx) * stride;
+        const bool ok = row < g.vrows && (unsigned)(y + dy) < (unsigned)g.n && (unsigned)(x + dx) < (unsigned)g.n;
+        taptab[i] = (uint16_t)((ok ? src : zbase + (src & 255)) >> 4);
     }
 }
 

@@ -356,6 +356,9 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void k_tower(TowerParams P) {
     char* zrow = smem + ((ROWS * STRIDE + 255) / 256) * 256;
     char* bbuf = zrow + ZBYTES;
     float* scratch = (float*)bbuf;  // epilogue scratch shares the weight staging buffers
+    // LEAN: the tap table of gemm_conv_ring follows the squeeze-excite scratch (tower_lds_bytes)
+    uint16_t* taptab = (uint16_t*)(bbuf + ((((size_t)2 * P.TB * C + (size_t)P.TB * P.hid) * 4 + 16 + 15) & ~(size_t)15));
+    (void)taptab;
     const int tid = threadIdx.x;
     uint4* xres_wg = P.xres + (size_t)blockIdx.x * NV * NT;
 #ifdef AZ_STAMP
@@ -377,6 +380,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void k_tower(TowerParams P) {
         const int nb = min(P.TB, rows - board0);
         g.vrows = nb * P.np;  // valid rows of this workgroup
         __syncthreads();      // the previous item's last LDS reads are done
+        if constexpr (LEAN && WM == 1) build_tap_table(taptab, ROWS, STRIDE, (int)(zrow - act), g, tid, NT);
 
         // ---- stage 0: feature tile -> act (row stride 2*cin_pad+32)
         const int in_stride0 = 2 * P.cin_pad + 32;
@@ -410,7 +414,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void k_tower(TowerParams P) {
         const size_t conv_vecs = (size_t)NKS * 32 * C * 2 / 16;
         for (int blk = 0; blk < P.blocks; ++blk) {
             zero_acc<MI, NI>(acc);
-            if constexpr (LEAN && WM == 1) gemm_conv_ring<MI, NI, WN, C, KPT, GW, AZ_RING>(acc, P.w_tower + (size_t)(2 * blk) * conv_vecs, 9, true, act, STRIDE, zrow, g);
+            if constexpr (LEAN && WM == 1) gemm_conv_ring<MI, NI, WN, C, KPT, GW, AZ_RING>(acc, P.w_tower + (size_t)(2 * blk) * conv_vecs, 9, act, taptab);
             else if constexpr (SAME && GW > 0) gemm_conv_gw<MI, NI, WM, WN, C, KPT, GW>(acc, P.w_tower + (size_t)(2 * blk) * conv_vecs, 9, true, act, STRIDE, zrow, g);
             else if constexpr (SAME) gemm_conv<MI, NI, WM, WN, C, KPT>(acc, P.w_tower + (size_t)(2 * blk) * conv_vecs, 9, true, act, STRIDE, zrow, bbuf, g);
             else gemm_taps<MI, NI, WM, WN, C, false>(acc, P.w_tower + (size_t)(2 * blk) * conv_vecs, NKS, KPT, 9, true, act, STRIDE, zrow, bbuf, g);
@@ -418,7 +422,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void k_tower(TowerParams P) {
             store_act<MI, NI, WM, WN, STRIDE, true, false>(acc, P.b_tower + (size_t)(2 * blk) * C, act, xres_wg);
             STAMP(3);
             zero_acc<MI, NI>(acc);
-            if constexpr (LEAN && WM == 1) gemm_conv_ring<MI, NI, WN, C, KPT, GW, AZ_RING>(acc, P.w_tower + (size_t)(2 * blk + 1) * conv_vecs, 9, true, act, STRIDE, zrow, g);
+            if constexpr (LEAN && WM == 1) gemm_conv_ring<MI, NI, WN, C, KPT, GW, AZ_RING>(acc, P.w_tower + (size_t)(2 * blk + 1) * conv_vecs, 9, act, taptab);
             else if constexpr (SAME && GW > 0) gemm_conv_gw<MI, NI, WM, WN, C, KPT, GW>(acc, P.w_tower + (size_t)(2 * blk + 1) * conv_vecs, 9, true, act, STRIDE, zrow, g);
             else if constexpr (SAME) gemm_conv<MI, NI, WM, WN, C, KPT>(acc, P.w_tower + (size_t)(2 * blk + 1) * conv_vecs, 9, true, act, STRIDE, zrow, bbuf, g);
             else gemm_taps<MI, NI, WM, WN, C, false>(acc, P.w_tower + (size_t)(2 * blk + 1) * conv_vecs, NKS, KPT, 9, true, act, STRIDE, zrow, bbuf, g);
@@ -775,7 +779,8 @@ static size_t se_blob_bytes(int C, int hid) {  // per block: w1, w2^T (bf16), b1
 static size_t tower_lds_bytes(int C, int NH, int TB, int hid, int rows = 256, bool lean = false) {
     const size_t stride = 2 * C + 32;
     const size_t tile = lean ? 0 : (size_t)64 * std::max(C, NH) * 2;
-    const size_t se = ((size_t)2 * TB * C + (size_t)TB * hid) * 4 + 16 + (lean ? 0 : se_blob_bytes(C, hid));
+    const size_t se = lean ? ((((size_t)2 * TB * C + (size_t)TB * hid) * 4 + 16 + 15) & ~(size_t)15) + (size_t)9 * rows * 2   // + tap table
+                           : ((size_t)2 * TB * C + (size_t)TB * hid) * 4 + 16 + se_blob_bytes(C, hid);
     const size_t zbytes = ((256 + 2 * (size_t)C + 16 + 127) / 128) * 128;
     return (((size_t)rows * stride + 255) / 256) * 256 + zbytes + std::max(2 * tile, se);
 }

@@ -12,6 +12,8 @@ def main():
     torch.manual_seed(0)
     net = AlphaZeroNet(board_size=n, channels=ch, num_blocks=blocks).eval().to("cuda:0")
     nn = net.native("bf16")
+    if __import__("os").environ.get("AZ_BENCH_GRID"):   # limit the resident workgroups (diagnostics)
+        nn.set_tower_workgroups(int(__import__("os").environ["AZ_BENCH_GRID"]))
     f = (torch.rand((rows, n * n, 32), device="cuda:0") < 0.3).to(torch.bfloat16)
     f[:, :, 21:] = 0
     for _ in range(3):
