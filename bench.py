@@ -222,7 +222,7 @@ def launch_ranks(n, argv):
     """Start one rank per GPU as fresh child processes (this process has not touched the GPU) and relay their output."""
     import torch
     have = torch.cuda.device_count()          # counting devices does not initialise the GPU
-    if have < n:
+    if have < n and "--rehearse-on-one-gpu" not in argv:
         raise SystemExit(f"bench.py --gpus {n}: this host shows {have} GPU(s); refusing to report a {n}-GPU figure from fewer ranks")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.abspath(__file__), *argv]
@@ -244,6 +244,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="search time per CPU-baseline leg")
     ap.add_argument("--no-side-legs", action="store_true", help="skip the no-dedup window, the kernel census and the plies-per-game run")
     ap.add_argument("--force-dist", action="store_true", help="N=1: still go through a one-rank RCCL process group")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="test only: all ranks share GPU 0 and synchronise over gloo with host tensors (RCCL refuses two ranks on one "
+                         "device); exercises the N-rank control flow on a one-GPU box, its figures mean nothing")
     a = ap.parse_args()
     wl = WORKLOADS[a.config]
     a.games = a.games or wl["games"]
@@ -262,6 +265,8 @@ def main():
         raise SystemExit(f"bench.py --gpus {a.gpus} was started with WORLD_SIZE={world}: the two must agree")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
+    if a.rehearse_on_one_gpu:
+        local = 0
     if local >= torch.cuda.device_count():
         raise SystemExit(f"rank {rank}: no GPU {local} on this host ({torch.cuda.device_count()} visible)")
     torch.cuda.set_device(local)
@@ -271,7 +276,10 @@ def main():
         if not in_launcher:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", str(free_port()))
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if a.rehearse_on_one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         world = dist.get_world_size()
 
     from alphazero_amd.model import AlphaZeroNet
@@ -310,19 +318,21 @@ def main():
 
     c = dict(sp.counters)
     mine = torch.tensor([dt, c["sims"], c["nn_rows"], c["nn_rows_nodedup"], c["moves"], c["games"], c["depth_sum"]],
-                        dtype=torch.float64, device=dev)
+                        dtype=torch.float64, device="cpu" if a.rehearse_on_one_gpu else dev)
     if dist is not None:
         tmax = mine[:1].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tot = mine.clone()
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         dt_max, tot = float(tmax[0]), tot.cpu().tolist()
+        # the collectives end here, for every rank: what follows (side legs, CPU baseline) is rank 0's alone, and a
+        # barrier inside it would have no partner
+        dist.barrier()
+        dist.destroy_process_group()
+        dist = None
     else:
         dt_max, tot = dt, mine.cpu().tolist()
     if rank != 0:
-        if dist is not None:
-            dist.barrier()
-            dist.destroy_process_group()
         return
 
     sims, rows, rows_raw, moves, games, depth_sum = tot[1:]
@@ -380,9 +390,6 @@ def main():
                                           f"{sp2.counters['sims']} simulations), as upstream does")
             del sp2
         out["roofline_other"], out["roofline_other_setup"] = kernel_census(net, a.batch, a.games)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
     if world == 1 and not a.no_cpu_baseline and headline:
         try:
             out["cpu_baseline"] = cpu_baseline(a.batch, a.cpu_seconds)

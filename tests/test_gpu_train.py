@@ -265,3 +265,25 @@ def test_bench_rank_launch(tmp_path):
                          capture_output=True, text=True, timeout=120, cwd=root,
                          env=dict(env, RANK="0", WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port())))
     assert bad.returncode != 0 and "must agree" in bad.stderr
+
+
+@pytest.mark.gpu
+def test_bench_two_rank_control_flow():
+    """The N-rank flow of bench.py with N = 2 on one GPU (both ranks on GPU 0, gloo with host tensors instead of RCCL,
+    which refuses two ranks on one device): barriers around the timed window pair up on every rank, the counters are
+    summed over the ranks, only rank 0 prints, and rank 0's side legs (no-dedup window, kernel census, plies per game)
+    run after the process group is gone, so no barrier of theirs waits for ranks that have left."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    run = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse-on-one-gpu", "--steps", "2", "--warmup", "1",
+                          "--games", "128", "--lanes", "2", "--no-cpu-baseline"], capture_output=True, text=True, timeout=420, cwd=root, env=env)
+    assert run.returncode == 0, run.stderr[-3000:]
+    lines = [ln for ln in run.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, run.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
+    # 2 ranks x 128 games x 256 simulations per step
+    assert abs(d["value"] * d["ms_per_step"] * 1e-3 / (2 * 128 * 256) - 1.0) < 1e-3   # the printed figures are rounded
+    assert d["value_no_dedup"] > 0 and len(d["roofline_other"]) == 3 and d["games_per_hour"] > 0
