@@ -211,7 +211,16 @@ __device__ inline void legal_points(const Geo<PPL>& g, const BoardLds<PPL>& b, c
         legal[k] = haslib;  // false = suicide
         key[k] = hash ^ zob[2 * p + (color < 0)] ^ hx ^ side_after;
     }
-    for (int i = 0; i < ns; ++i) {  // situational superko
+    // situational superko: every lane compares its candidate keys with every seen key (the same address in all lanes:
+    // LDS broadcasts); four keys per trip so that the reads of a trip are in flight together
+    int i = 0;
+    for (; i + 4 <= ns; i += 4) {
+        const uint64_t s0 = seen[i], s1 = seen[i + 1], s2 = seen[i + 2], s3 = seen[i + 3];
+#pragma unroll
+        for (int k = 0; k < PPL; ++k)
+            if (key[k] == s0 || key[k] == s1 || key[k] == s2 || key[k] == s3) legal[k] = false;
+    }
+    for (; i < ns; ++i) {
         const uint64_t s = seen[i];
 #pragma unroll
         for (int k = 0; k < PPL; ++k)

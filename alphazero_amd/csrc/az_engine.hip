@@ -289,30 +289,39 @@ __device__ inline int emit_features(const Dev& d, int lane, const Geo<PPL>& geo,
                 o[(2 * d.H + 3) * d.np + p] = f_own;
                 o[(2 * d.H + 4) * d.np + p] = f_opp;
             }
-        } else {  // bf16 [np][cpad], channel-minor
+        } else {  // bf16 [np][cpad], channel-minor: a point's channels are assembled in registers, 16 bytes per store
             const int cpad = d.C <= 32 ? 32 : 64;
-            uint16_t* o = (uint16_t*)out_row;
-            const uint16_t one = 0x3F80;
-            auto bf = [](float f) -> uint16_t {  // round to nearest even
+            const uint32_t one = 0x3F80u;
+            auto bf = [](float f) -> uint32_t {  // round to nearest even
                 uint32_t u = __float_as_uint(f);
-                return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+                return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
             };
+            const uint32_t w_own = bf(f_own), w_opp = bf(f_opp), w_tp = s.tp > 0 ? one : 0u;
+            const int H = d.H;
 #pragma unroll
             for (int k = 0; k < PPL; ++k) {
                 const int p = geo.p[k];
                 if (p < 0) continue;
-                uint16_t* op = o + (size_t)p * cpad;
-                for (int i = 0; i < d.H; ++i) {
-                    const int v = i < take ? hist[i * hist_stride + p] : 0;
-                    op[i] = (v != 0 && v == s.tp) ? one : 0;
-                    op[d.H + i] = (v != 0 && v == -s.tp) ? one : 0;
+                const uint32_t w_legal = legal[k] ? one : 0u, w_last = p == s.last ? one : 0u;
+                auto chan = [&](int c) -> uint32_t {   // plane c of point p (go.py:270-302)
+                    if (c < 2 * H) {
+                        const int i = c < H ? c : c - H, want = c < H ? s.tp : -s.tp;
+                        const int v = i < take ? hist[i * hist_stride + p] : 0;
+                        return v == want ? one : 0u;   // want is +-1, so v != 0 is implied
+                    }
+                    c -= 2 * H;
+                    return c == 0 ? w_tp : c == 1 ? w_legal : c == 2 ? w_last : c == 3 ? w_own : c == 4 ? w_opp : 0u;
+                };
+                uint4* op = (uint4*)((uint16_t*)out_row + (size_t)p * cpad);
+                for (int q = 0; q < cpad / 8; ++q) {
+                    const int c0 = 8 * q;
+                    uint4 v;
+                    v.x = chan(c0) | (chan(c0 + 1) << 16);
+                    v.y = chan(c0 + 2) | (chan(c0 + 3) << 16);
+                    v.z = chan(c0 + 4) | (chan(c0 + 5) << 16);
+                    v.w = chan(c0 + 6) | (chan(c0 + 7) << 16);
+                    op[q] = v;
                 }
-                op[2 * d.H] = s.tp > 0 ? one : 0;
-                op[2 * d.H + 1] = legal[k] ? one : 0;
-                op[2 * d.H + 2] = p == s.last ? one : 0;
-                op[2 * d.H + 3] = bf(f_own);
-                op[2 * d.H + 4] = bf(f_opp);
-                for (int c = d.C; c < cpad; ++c) op[c] = 0;
             }
         }
     }
@@ -644,9 +653,9 @@ __global__ __launch_bounds__(64) void k_leaf(Dev d, void* out, int layout) {
     geo_init<PPL>(geo, d.n, lane);
     Sim<PPL> s;
     sim_load_root<PPL>(d, g, lane, geo, b, seen_lds, s);
-    for (int i = lane; i < d.H * BoardLds<PPL>::NPAD; i += 64) {
-        const int hi = i / BoardLds<PPL>::NPAD, p = i % BoardLds<PPL>::NPAD;
-        hist_lds[i] = d.hist[((size_t)g * d.H + hi) * d.npad + p];
+    {   // the game's H history boards are contiguous ([H][npad], npad = NPAD, a multiple of 64): 16 bytes per load
+        const uint4* src = (const uint4*)(d.hist + (size_t)g * d.H * d.npad);
+        for (int i = lane; i < d.H * BoardLds<PPL>::NPAD / 16; i += 64) ((uint4*)hist_lds)[i] = src[i];
     }
     int hist_count = d.sc[sc_idx(g, SC_HIST)];
     __syncthreads();
