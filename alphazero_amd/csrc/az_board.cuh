@@ -24,6 +24,14 @@ __host__ __device__ inline uint64_t zobrist_key(int index) {
     return splitmix64(0x5A0B1D5EED5EEDULL + (uint64_t)(index + 1) * 0x9E3779B97F4A7C15ULL);
 }
 
+// Ordering point for a workgroup that is one wave (every kernel that uses this file): LDS accesses of one wave execute
+// in issue order, so lanes see each other's earlier LDS writes once the compiler keeps the order; unlike __syncthreads
+// this does not wait for outstanding global loads and stores, which may then overlap the board analysis.
+__device__ inline void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // Per-lane geometry: owned points and their four neighbours (-1 = off board / unused slot).
 template <int PPL>
 struct Geo {
@@ -78,7 +86,7 @@ __device__ inline void analyze(const Geo<PPL>& g, BoardLds<PPL>& b, const uint64
             b.gz[p] = 0;
         }
     }
-    __syncthreads();
+    wave_sync();
 #pragma unroll
     for (int k = 0; k < PPL; ++k) {
         same[k] = 0;
@@ -107,7 +115,7 @@ __device__ inline void analyze(const Geo<PPL>& g, BoardLds<PPL>& b, const uint64
                 }
             }
         }
-        __syncthreads();
+        wave_sync();
         if (!__any(changed)) break;
     }
 #pragma unroll
@@ -139,7 +147,7 @@ __device__ inline void analyze(const Geo<PPL>& g, BoardLds<PPL>& b, const uint64
             }
         }
     }
-    __syncthreads();
+    wave_sync();
 }
 
 // Place a stone of `color` at p on an analysed board: remove the opponent groups whose only liberty
@@ -157,7 +165,7 @@ __device__ inline int place_stone(const Geo<PPL>& g, BoardLds<PPL>& b, const uin
     if (q1 >= 0 && b.col[q1] == -color) { int rr = b.lab[q1]; if (b.lib[rr] == 1 && rr != c0) { c1 = rr; captured += b.gsz[rr]; hx ^= b.gz[rr]; } }
     if (q2 >= 0 && b.col[q2] == -color) { int rr = b.lab[q2]; if (b.lib[rr] == 1 && rr != c0 && rr != c1) { c2 = rr; captured += b.gsz[rr]; hx ^= b.gz[rr]; } }
     if (q3 >= 0 && b.col[q3] == -color) { int rr = b.lab[q3]; if (b.lib[rr] == 1 && rr != c0 && rr != c1 && rr != c2) { c3 = rr; captured += b.gsz[rr]; hx ^= b.gz[rr]; } }
-    __syncthreads();
+    wave_sync();
     if (captured) {
 #pragma unroll
         for (int k = 0; k < PPL; ++k) {
@@ -170,7 +178,7 @@ __device__ inline int place_stone(const Geo<PPL>& g, BoardLds<PPL>& b, const uin
     }
     if (lane == (p & 63)) b.col[p] = (int8_t)color;
     hash ^= zob[2 * p + (color < 0)] ^ hx;
-    __syncthreads();
+    wave_sync();
     return captured;
 }
 

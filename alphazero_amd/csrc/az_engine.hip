@@ -104,7 +104,7 @@ __device__ inline void sim_load_root(const Dev& d, int g, int lane, const Geo<PP
     s.ns = d.sc[sc_idx(g, SC_SEEN)];
     s.hash = d.hash[g];
     for (int i = lane; i < s.ns; i += 64) seen_lds[i] = d.seen[(size_t)g * d.seen_cap + i];
-    __syncthreads();
+    wave_sync();
 }
 
 template <int PPL>
@@ -140,7 +140,7 @@ __device__ inline void sim_play(const Dev& d, int lane, const Geo<PPL>& geo, Boa
         for (int k = 0; k < PPL; ++k)
             if (geo.p[k] >= 0) hist_lds[geo.p[k]] = b.col[geo.p[k]];
     }
-    __syncthreads();
+    wave_sync();
 }
 
 // go.py:251-263 for a terminal replayed state.
@@ -482,14 +482,44 @@ __global__ __launch_bounds__(1024) void k_scan_rows(Dev d, int root_phase) {
     if (t == 1023) { d.row_off[d.G] = n_all; d.ctl[0] = n_eval; d.ctl[2] = n_all; }
 }
 
-// (score, index) arg-max over the wave: largest score, smallest index among equals.
+// (score, index) arg-max over the wave: largest score, smallest index among equals (idx must be unique per lane, or
+// 0x7fffffff with score -inf). The maximum is reduced with DPP row shifts / row broadcasts (register-to-register, no LDS
+// round trip per step as a lane shuffle has): after the four row_shr steps lane 15 of every row of 16 holds its row's
+// maximum, the two row_bcast steps fold the rows into lane 63. The index follows from a ballot of the lanes that hold
+// the maximum. NaN scores never win (they compare false), as in a sequential scan that starts at -inf.
+__device__ inline double wave_max_f64(double v) {
+    auto step = [&](auto ctrl, auto row_mask) {
+        const int lo = __double2loint(v), hi = __double2hiint(v);
+        const int ninf_hi = (int)0xFFF00000;   // lanes a step does not reach combine with -inf
+        const int olo = __builtin_amdgcn_update_dpp(0, lo, decltype(ctrl)::value, decltype(row_mask)::value, 0xf, false);
+        const int ohi = __builtin_amdgcn_update_dpp(ninf_hi, hi, decltype(ctrl)::value, decltype(row_mask)::value, 0xf, false);
+        const double o = __hiloint2double(ohi, olo);
+        if (o > v) v = o;
+    };
+    step(std::integral_constant<int, 0x111>{}, std::integral_constant<int, 0xf>{});   // row_shr:1
+    step(std::integral_constant<int, 0x112>{}, std::integral_constant<int, 0xf>{});   // row_shr:2
+    step(std::integral_constant<int, 0x114>{}, std::integral_constant<int, 0xf>{});   // row_shr:4
+    step(std::integral_constant<int, 0x118>{}, std::integral_constant<int, 0xf>{});   // row_shr:8
+    step(std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});   // row_bcast:15 into rows 1 and 3
+    step(std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});   // row_bcast:31 into rows 2 and 3
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+__device__ inline double readlane_f64(double v, int lane_index) {   // lane_index must be wave-uniform
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane_index), __builtin_amdgcn_readlane(__double2loint(v), lane_index));
+}
 __device__ inline void wave_argmax(double& s, int& idx) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const double os = __shfl_xor(s, o);
-        const int oi = __shfl_xor(idx, o);
-        if (os > s || (os == s && oi < idx)) { s = os; idx = oi; }
-    }
+    const double m = wave_max_f64(s);
+    // every lane's candidate is its own index here (one child per lane and trip), or the lane's best over several trips:
+    // among the lanes that hold the maximum the smallest index wins
+    int cand = (s == m && idx != 0x7fffffff) ? idx : 0x7fffffff;
+    cand = min(cand, __builtin_amdgcn_update_dpp(0x7fffffff, cand, 0x111, 0xf, 0xf, false));
+    cand = min(cand, __builtin_amdgcn_update_dpp(0x7fffffff, cand, 0x112, 0xf, 0xf, false));
+    cand = min(cand, __builtin_amdgcn_update_dpp(0x7fffffff, cand, 0x114, 0xf, 0xf, false));
+    cand = min(cand, __builtin_amdgcn_update_dpp(0x7fffffff, cand, 0x118, 0xf, 0xf, false));
+    cand = min(cand, __builtin_amdgcn_update_dpp(0x7fffffff, cand, 0x142, 0xa, 0xf, false));
+    cand = min(cand, __builtin_amdgcn_update_dpp(0x7fffffff, cand, 0x143, 0xc, 0xf, false));
+    s = m; idx = __builtin_amdgcn_readlane(cand, 63);
 }
 
 // mcts.py:181-199: batch_n descents for game blockIdx.x.
@@ -530,6 +560,10 @@ __global__ __launch_bounds__(64) void k_select(Dev d, int batch_n) {
         c_prior = prior[rfirst + lane]; c_vsum = vsum[rfirst + lane]; c_vis = visits[rfirst + lane];
         c_nch = n_child[rfirst + lane]; c_act = action[rfirst + lane];
     }
+    // the root's visit count during descent `slot` is r_vis + slot with virtual loss (else r_vis): lane i holds the
+    // exploration-table entries of r_vis + i, so the descents from the root start without a dependent table load
+    const int t_idx = min(r_vis + (d.vl > 0.0 ? lane : 0), d.tab_len - 1);
+    const double t_pbc = d.pbc[t_idx], t_sqn = d.sqn[t_idx];
     for (int slot = 0; slot < batch_n; ++slot) {
         int* path = d.path + ((size_t)g * d.B + slot) * d.max_depth;
         int node = 0, len = 1, nc = rnc;
@@ -542,9 +576,14 @@ __global__ __launch_bounds__(64) void k_select(Dev d, int batch_n) {
             // mcts.py:97-116
             const bool at_root = cached && node == 0;
             const int first = at_root ? rfirst : child_off[node];
-            int pv = at_root ? r_vis : (child_vis >= 0 ? child_vis : visits[node]);
-            pv = pv < d.tab_len ? pv : d.tab_len - 1;
-            const double pbc = d.pbc[pv], sq = d.sqn[pv];
+            double pbc, sq;
+            if (at_root && slot < 64) {   // slot is wave-uniform: register reads, no lane shuffle
+                pbc = readlane_f64(t_pbc, slot); sq = readlane_f64(t_sqn, slot);
+            } else {
+                int pv = at_root ? r_vis : (child_vis >= 0 ? child_vis : visits[node]);
+                pv = pv < d.tab_len ? pv : d.tab_len - 1;
+                pbc = d.pbc[pv]; sq = d.sqn[pv];
+            }
             double best = -INFINITY;
             int best_i = 0x7fffffff;
             for (int i0 = 0; i0 < nc; i0 += 64) {
@@ -561,16 +600,17 @@ __global__ __launch_bounds__(64) void k_select(Dev d, int batch_n) {
             wave_argmax(best, best_i);
             if (best_i == 0x7fffffff) { failed = true; break; }  // mcts.py:114-115
             node = first + best_i;
-            const int act = at_root ? __shfl(c_act, best_i) : (int)action[node];
-            nc = at_root ? __shfl(c_nch, best_i) : (int)n_child[node];
-            child_vis = at_root ? __shfl(c_vis, best_i) : -1;
+            // best_i is wave-uniform (wave_argmax returns it from one lane)
+            const int act = at_root ? __builtin_amdgcn_readlane(c_act, best_i) : (int)action[node];
+            nc = at_root ? __builtin_amdgcn_readlane(c_nch, best_i) : (int)n_child[node];
+            child_vis = at_root ? __builtin_amdgcn_readlane(c_vis, best_i) : -1;
             passes = act == d.np ? passes + 1 : 0;
             moves += 1;
             if (lane == 0) path_lds[len] = node;
             len += 1;
         }
         if (failed) { if (lane == 0) atomicMin(&d.ctl[1], (int)AZ_ERR_NOCHILD); }
-        __syncthreads();
+        wave_sync();
         for (int i = lane; i < len; i += 64) path[i] = path_lds[i];
         const bool terminal = passes >= 2 || moves >= 2 * d.np;
         Sim<PPL> s = root;
@@ -606,7 +646,7 @@ __global__ __launch_bounds__(64) void k_select(Dev d, int batch_n) {
         if (lane == 0) { d.path_len[gs] = len; d.leaf_ref[gs] = ref; }
         depth_sum += len - 1;
         max_depth = max(max_depth, len - 1);
-        __syncthreads();
+        wave_sync();
         if (d.vl > 0.0) {  // mcts.py:196-199
             if (cached) {
                 r_vis += 1;
@@ -619,8 +659,7 @@ __global__ __launch_bounds__(64) void k_select(Dev d, int batch_n) {
                 vsum[pn] -= d.vl;
             }
         }
-        __threadfence_block();
-        __syncthreads();
+        wave_sync();
     }
     if (cached) {
         if (lane < rnc) { visits[rfirst + lane] = c_vis; vsum[rfirst + lane] = c_vsum; }
@@ -658,7 +697,7 @@ __global__ __launch_bounds__(64) void k_leaf(Dev d, void* out, int layout) {
         for (int i = lane; i < d.H * BoardLds<PPL>::NPAD / 16; i += 64) ((uint4*)hist_lds)[i] = src[i];
     }
     int hist_count = d.sc[sc_idx(g, SC_HIST)];
-    __syncthreads();
+    wave_sync();
     if (slot >= 0) {
         const int len = d.path_len[g * d.B + slot];
         const int* path = d.path + ((size_t)g * d.B + slot) * d.max_depth;
