@@ -531,6 +531,12 @@ __global__ __launch_bounds__(64) void k_select(Dev d, int batch_n) {
     uint64_t* seen_lds = (uint64_t*)dyn;
     int* path_lds = (int*)(seen_lds + d.seen_cap);   // the current descent's nodes
     int* uniq_lds = path_lds + d.max_depth;          // (slot, leaf node) of the batch's distinct leaves so far
+    // Per-descent results wait in LDS and go to global memory after the last descent: stores and loads share one
+    // counter, so a store in flight would stall the next descent at its first wait for a load (about 2 us each).
+    constexpr int PSTAGE = 8;                        // path nodes staged per descent; a longer path is written at once
+    int* st_len = uniq_lds + 2 * d.B;                // [B]
+    int* st_ref = st_len + d.B;                      // [B]
+    int* st_path = st_ref + d.B;                     // [B][PSTAGE]
     const int g = blockIdx.x, lane = threadIdx.x;
     if (!d.active[g]) { if (lane == 0) d.n_unique[g] = 0; return; }
     Geo<PPL> geo;
@@ -611,7 +617,8 @@ __global__ __launch_bounds__(64) void k_select(Dev d, int batch_n) {
         }
         if (failed) { if (lane == 0) atomicMin(&d.ctl[1], (int)AZ_ERR_NOCHILD); }
         wave_sync();
-        for (int i = lane; i < len; i += 64) path[i] = path_lds[i];
+        if (len <= PSTAGE) { if (lane < len) st_path[slot * PSTAGE + lane] = path_lds[lane]; }
+        else for (int i = lane; i < len; i += 64) path[i] = path_lds[i];
         const bool terminal = passes >= 2 || moves >= 2 * d.np;
         Sim<PPL> s = root;
         if (terminal) {
@@ -636,14 +643,13 @@ __global__ __launch_bounds__(64) void k_select(Dev d, int batch_n) {
             }
             if (ref == slot) {
                 if (lane == 0) {
-                    d.uniq_slot[g * d.B + n_unique] = slot;
                     uniq_lds[2 * n_unique] = slot;
                     uniq_lds[2 * n_unique + 1] = node;
                 }
                 n_unique += 1;
             }
         }
-        if (lane == 0) { d.path_len[gs] = len; d.leaf_ref[gs] = ref; }
+        if (lane == 0) { st_len[slot] = len; st_ref[slot] = ref; }
         depth_sum += len - 1;
         max_depth = max(max_depth, len - 1);
         wave_sync();
@@ -665,6 +671,16 @@ __global__ __launch_bounds__(64) void k_select(Dev d, int batch_n) {
         if (lane < rnc) { visits[rfirst + lane] = c_vis; vsum[rfirst + lane] = c_vsum; }
         if (lane == 0) { visits[0] = r_vis; vsum[0] = r_vsum; }
     }
+    for (int sl = lane; sl < batch_n; sl += 64) {
+        const int len = st_len[sl];
+        d.path_len[g * d.B + sl] = len;
+        d.leaf_ref[g * d.B + sl] = st_ref[sl];
+        if (len <= PSTAGE) {
+            int* path = d.path + ((size_t)g * d.B + sl) * d.max_depth;
+            for (int i = 0; i < len; ++i) path[i] = st_path[sl * PSTAGE + i];
+        }
+    }
+    for (int u = lane; u < n_unique; u += 64) d.uniq_slot[g * d.B + u] = uniq_lds[2 * u];
     if (lane == 0) {
         d.n_unique[g] = n_unique;
         long long* gs = d.gstats + (size_t)g * 8;
@@ -1265,7 +1281,7 @@ int az_mcts_select(az_engine* e, void* stream) {
     if (!e) return fail(AZ_ERR_ARG, "null engine");
     if (e->phase != PH_NEED_SELECT) return fail(AZ_ERR_STATE, "az_mcts_select: no batch to select (expand the pending rows first)");
     e->batch_n = std::min(e->d.B, e->d.sims - e->sims_done);
-    DISPATCH_PPL(e, k_select, e->d.G, seen_bytes(e) + ((size_t)e->d.max_depth + 2 * (size_t)e->d.B) * 4, stream, e->d, e->batch_n);
+    DISPATCH_PPL(e, k_select, e->d.G, seen_bytes(e) + ((size_t)e->d.max_depth + (2 + 2 + 8) * (size_t)e->d.B) * 4, stream, e->d, e->batch_n);   // path, uniq pairs, staged len / ref / path[8]
     hipLaunchKernelGGL(k_scan_rows, dim3(1), dim3(1024), 0, (hipStream_t)stream, e->d, 0);
     e->phase = PH_SELECTED;
     e->rows_known = false;
