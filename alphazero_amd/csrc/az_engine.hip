@@ -529,7 +529,8 @@ __global__ __launch_bounds__(64) void k_select(Dev d, int batch_n) {
     __shared__ int8_t root_col[BoardLds<PPL>::NPAD];
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
     uint64_t* seen_lds = (uint64_t*)dyn;
-    int* path_lds = (int*)(seen_lds + d.seen_cap);   // the current descent's nodes
+    double* tc_val = (double*)(seen_lds + d.seen_cap);   // outcomes of the terminal leaves met in this batch ...
+    int* path_lds = (int*)(tc_val + d.B);            // the current descent's nodes
     int* uniq_lds = path_lds + d.max_depth;          // (slot, leaf node) of the batch's distinct leaves so far
     // Per-descent results wait in LDS and go to global memory after the last descent: stores and loads share one
     // counter, so a store in flight would stall the next descent at its first wait for a load (about 2 us each).
@@ -537,6 +538,8 @@ __global__ __launch_bounds__(64) void k_select(Dev d, int batch_n) {
     int* st_len = uniq_lds + 2 * d.B;                // [B]
     int* st_ref = st_len + d.B;                      // [B]
     int* st_path = st_ref + d.B;                     // [B][PSTAGE]
+    int* tc_node = st_path + d.B * PSTAGE;           // ... and their nodes: with virtual loss the descents of a batch mostly end
+    int n_tc = 0;                                    // in the same leaf, and a terminal one is replayed and scored once
     const int g = blockIdx.x, lane = threadIdx.x;
     if (!d.active[g]) { if (lane == 0) d.n_unique[g] = 0; return; }
     Geo<PPL> geo;
@@ -620,18 +623,26 @@ __global__ __launch_bounds__(64) void k_select(Dev d, int batch_n) {
         if (len <= PSTAGE) { if (lane < len) st_path[slot * PSTAGE + lane] = path_lds[lane]; }
         else for (int i = lane; i < len; i += 64) path[i] = path_lds[i];
         const bool terminal = passes >= 2 || moves >= 2 * d.np;
-        Sim<PPL> s = root;
-        if (terminal) {
-#pragma unroll
-            for (int k = 0; k < PPL; ++k)
-                if (geo.p[k] >= 0) b.col[geo.p[k]] = root_col[geo.p[k]];
-            __syncthreads();
-            for (int i = 1; i < len; ++i) sim_play<PPL>(d, lane, geo, b, seen_lds, nullptr, s, (int)action[path_lds[i]]);
-        }
         const int gs = g * d.B + slot;
         int ref;
         if (terminal) {  // mcts.py:191-192
-            const double v = sim_outcome<PPL>(d, geo, b, s);
+            int hit = -1;
+            for (int u = 0; u < n_tc; ++u)
+                if (tc_node[u] == node) { hit = u; break; }
+            double v;
+            if (hit >= 0) {
+                v = tc_val[hit];
+            } else {
+                Sim<PPL> s = root;
+#pragma unroll
+                for (int k = 0; k < PPL; ++k)
+                    if (geo.p[k] >= 0) b.col[geo.p[k]] = root_col[geo.p[k]];
+                __syncthreads();
+                for (int i = 1; i < len; ++i) sim_play<PPL>(d, lane, geo, b, seen_lds, nullptr, s, (int)action[path_lds[i]]);
+                v = sim_outcome<PPL>(d, geo, b, s);
+                if (lane == 0) { tc_node[n_tc] = node; tc_val[n_tc] = v; }
+                n_tc += 1;
+            }
             if (lane == 0) d.term_value[gs] = v;
             ref = -1;
             n_term += 1;
@@ -1281,7 +1292,7 @@ int az_mcts_select(az_engine* e, void* stream) {
     if (!e) return fail(AZ_ERR_ARG, "null engine");
     if (e->phase != PH_NEED_SELECT) return fail(AZ_ERR_STATE, "az_mcts_select: no batch to select (expand the pending rows first)");
     e->batch_n = std::min(e->d.B, e->d.sims - e->sims_done);
-    DISPATCH_PPL(e, k_select, e->d.G, seen_bytes(e) + ((size_t)e->d.max_depth + (2 + 2 + 8) * (size_t)e->d.B) * 4, stream, e->d, e->batch_n);   // path, uniq pairs, staged len / ref / path[8]
+    DISPATCH_PPL(e, k_select, e->d.G, seen_bytes(e) + ((size_t)e->d.max_depth + (2 + 2 + 8 + 1 + 2) * (size_t)e->d.B) * 4, stream, e->d, e->batch_n);   // path, uniq pairs, staged len / ref / path[8], terminal-leaf cache (node, value)
     hipLaunchKernelGGL(k_scan_rows, dim3(1), dim3(1024), 0, (hipStream_t)stream, e->d, 0);
     e->phase = PH_SELECTED;
     e->rows_known = false;

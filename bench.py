@@ -192,6 +192,8 @@ def kernel_census(net, batch, games, plies=24):
         t0 = ev(); t1 = ev()
         t0.record(); done = eng.expand(lg, v); t1.record(); t1.synchronize()
         t_sel += e[0].elapsed_time(e[1]); t_leaf += e[2].elapsed_time(e[3]); t_exp += t0.elapsed_time(t1)
+        if os.environ.get("AZ_CENSUS_VERBOSE"):
+            print(f"round {n_rounds}: select {e[0].elapsed_time(e[1]) * 1e3:.0f} us, leaf {e[2].elapsed_time(e[3]) * 1e3:.0f} us, expand {t0.elapsed_time(t1) * 1e3:.0f} us, rows {rows}", file=sys.stderr)
         n_rounds += 1
         leaves += rows
     st = eng.stats()

@@ -9,5 +9,6 @@ from alphazero_amd.model import AlphaZeroNet
 games = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 torch.manual_seed(0)
 net = AlphaZeroNet(board_size=9, channels=bench.CH, num_blocks=bench.BLOCKS).eval().to("cuda:0")
-out, setup = bench.kernel_census(net, 16, games)
+plies = int(sys.argv[2]) if len(sys.argv) > 2 else 24
+out, setup = bench.kernel_census(net, 16, games, plies)
 print(" | ".join(f"{o['kernel']}: {o['avg_launch_us']} us" for o in out), setup)
