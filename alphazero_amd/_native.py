@@ -52,6 +52,8 @@ SIGNATURES = {
     "az_mcts_set_root_reuse": (_I32, [_VP, _I32]),
     "az_mcts_gather_rows": (_I32, [_VP, C.POINTER(_I32), _VP]),
     "az_mcts_set_async": (_I32, [_VP, _I32]),
+    "az_mcts_run_rounds": (_I32, [_VP, _VP, _VP, _I32, _VP, _VP, _I32, _VP]),
+    "az_net_capturable": (_I32, [_VP, _I32]),
     "az_mcts_rows_device": (_I32, [_VP, C.POINTER(_VP)]),
     "az_mcts_gather": (_I32, [_VP, _VP, _I32, _VP]),
     "az_mcts_row_games": (_I32, [_VP, _VP, _VP]),

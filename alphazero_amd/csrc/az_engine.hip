@@ -1098,6 +1098,9 @@ struct az_engine {
     long long* stats_host = nullptr;
     double* last_priors = nullptr;  // [max_rows][A]
     std::vector<void*> allocs;
+    // az_mcts_run_rounds: the launches of all remaining batch rounds of a search, captured once and replayed per move
+    hipGraphExec_t rounds_exec = nullptr;
+    const void* rounds_key[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // net, features, logits, values, (layout, first batch)
 };
 
 #define DISPATCH_PPL(e, KERNEL, grid, shmem, stream, ...)                                              \
@@ -1212,6 +1215,7 @@ int az_engine_destroy(az_engine* e) {
     if (!e) return AZ_OK;
     (void)hipSetDevice(e->cfg.device);
     (void)hipDeviceSynchronize();
+    if (e->rounds_exec) (void)hipGraphExecDestroy(e->rounds_exec);
     for (void* p : e->allocs) (void)hipFree(p);
     if (e->ctl_host) (void)hipHostFree(e->ctl_host);
     if (e->stats_host) (void)hipHostFree(e->stats_host);
@@ -1415,6 +1419,60 @@ int az_mcts_expand(az_engine* e, const float* logits, const float* values, const
     if (e->sims_done >= e->d.sims) { e->phase = PH_DONE; return 1; }
     e->phase = PH_NEED_SELECT;
     return 0;
+}
+
+// Enqueue the batch rounds from the engine's state (az_mcts_select .. az_mcts_expand until the simulations are used up).
+static int enqueue_rounds(az_engine* e, az_net* net, void* feat, int32_t layout, float* logits, float* values, void* stream) {
+    const int32_t max_rows = std::max(e->d.max_rows, e->d.G);
+    for (;;) {
+        int rc = az_mcts_select(e, stream);
+        if (rc != AZ_OK) return rc;
+        rc = az_mcts_gather(e, feat, layout, stream);
+        if (rc != AZ_OK) return rc;
+        rc = az_net_forward_indirect(net, feat, e->d.ctl, max_rows, logits, values, stream);
+        if (rc != AZ_OK) return rc;
+        rc = az_mcts_expand(e, logits, values, nullptr, stream);
+        if (rc < 0) return rc;
+        if (rc == 1) return AZ_OK;
+    }
+}
+
+int az_mcts_run_rounds(az_engine* e, az_net* net, void* feat, int32_t layout, float* logits, float* values, int32_t use_graph, void* stream) {
+    if (!e || !net || !feat || !logits || !values) return fail(AZ_ERR_ARG, "null argument");
+    if (!e->async_mode) return fail(AZ_ERR_STATE, "az_mcts_run_rounds needs asynchronous mode (az_mcts_set_async)");
+    if (e->phase == PH_DONE) return AZ_OK;
+    if (e->phase != PH_NEED_SELECT) return fail(AZ_ERR_STATE, "az_mcts_run_rounds: expand the root rows first");
+    const int32_t max_rows = std::max(e->d.max_rows, e->d.G);
+    // the legacy default stream cannot be captured
+    if (!use_graph || !stream || !az_net_capturable(net, max_rows)) return enqueue_rounds(e, net, feat, layout, logits, values, stream);
+    // One graph per (network, buffers, layout, simulations already done): the launch arguments of a move's rounds never
+    // change - row counts live on the device - so later moves replay it.
+    const void* key[5] = {net, feat, logits, values, (const void*)(uintptr_t)(((uint64_t)(uint32_t)layout << 32) | (uint32_t)e->sims_done)};
+    if (!e->rounds_exec || memcmp(key, e->rounds_key, sizeof(key)) != 0) {
+        if (e->rounds_exec) { (void)hipGraphExecDestroy(e->rounds_exec); e->rounds_exec = nullptr; }
+        const int phase0 = e->phase, sims0 = e->sims_done;
+        hipGraph_t graph = nullptr;
+        if (hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+            (void)hipGetLastError();   // this stream cannot be captured: enqueue the rounds one by one
+            return enqueue_rounds(e, net, feat, layout, logits, values, stream);
+        }
+        const int rc = enqueue_rounds(e, net, feat, layout, logits, values, stream);
+        const hipError_t ec = hipStreamEndCapture((hipStream_t)stream, &graph);
+        e->phase = phase0; e->sims_done = sims0; e->rows_known = false;   // nothing has run yet
+        if (rc != AZ_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+        if (ec != hipSuccess || !graph) return fail(AZ_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(ec));
+        const hipError_t ei = hipGraphInstantiate(&e->rounds_exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (ei != hipSuccess) { e->rounds_exec = nullptr; return fail(AZ_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ei)); }
+        memcpy(e->rounds_key, key, sizeof(key));
+    }
+    HIP_TRY(hipGraphLaunch(e->rounds_exec, (hipStream_t)stream));
+    { const int rem = e->d.sims - e->sims_done; e->batch_n = rem % e->d.B ? rem % e->d.B : e->d.B; }   // the last round's
+    e->sims_done = e->d.sims;
+    e->phase = PH_DONE;
+    e->rows_known = false;
+    e->last_rows = -1;
+    return 1;   // replayed from the graph
 }
 
 int az_mcts_root_legal_counts(az_engine* e, int32_t* counts, void* stream) {

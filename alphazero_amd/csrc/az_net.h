@@ -47,5 +47,6 @@ int mfma_reserve(MfmaNet* m, int rows);
 int mfma_forward_static(MfmaNet* m, const void* feat_bf16_nhwc, int rows, float* logits, float* values, hipStream_t st);
 long long mfma_static_max_rows(const MfmaNet* m);
 int mfma_indirect_passes(const MfmaNet* m, int max_rows);
+bool mfma_capturable(const MfmaNet* m, int max_rows);
 
 }  // namespace az

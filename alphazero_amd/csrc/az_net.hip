@@ -341,6 +341,11 @@ int az_net_indirect_passes(const az_net* net, int32_t max_rows) {
     return mfma_indirect_passes(net->mfma, max_rows);
 }
 
+int az_net_capturable(const az_net* net, int32_t max_rows) {
+    if (!net || !net->loaded || net->cfg.precision != AZ_NET_BF16 || max_rows < 1) return 0;
+    return mfma_capturable(net->mfma, max_rows) ? 1 : 0;
+}
+
 int64_t az_net_static_max_rows(const az_net* net) {
     if (!net || !net->loaded || net->cfg.precision != AZ_NET_BF16) return 0;
     return mfma_static_max_rows(net->mfma);

@@ -1249,6 +1249,12 @@ int mfma_indirect_passes(const MfmaNet* m, int max_rows) {
     return (max_rows + chunk - 1) / chunk;
 }
 
+// Whether an indirect forward over `max_rows` rows consists of kernel launches only, with nothing that a stream capture
+// could not record: one pass, scratch already reserved (no allocation), launch timing off (its events are per launch).
+bool mfma_capturable(const MfmaNet* m, int max_rows) {
+    return !m->profiling && mfma_indirect_passes(m, max_rows) == 1 && (m->layers ? true : max_rows <= m->hq_rows);
+}
+
 // rows_dev == null: `rows` positions. rows_dev != null: *rows_dev positions (read on the device, at most `rows`).
 int mfma_forward(MfmaNet* m, const void* feat, int rows, const int* rows_dev, float* logits, float* values, hipStream_t st) {
     const az_net_config& c = m->cfg;

@@ -10,7 +10,15 @@ import ctypes as C
 import numpy as np
 import torch
 
+import os
+
 from . import _native as N
+
+# AZ_GRAPH_ROUNDS=1: replay a captured HIP graph for the batch rounds of a search where the network allows it, instead of
+# enqueueing the rounds' kernels one by one. Same results; off by default because it measured no faster on any shape (the
+# rounds are a chain of dependent kernels, bound by their execution and not by their launches: 3.4 ms per move for 512
+# games of 64ch x 4 and 15.4 ms for a 40-game 256-simulation search either way).
+GRAPH_ROUNDS = os.environ.get("AZ_GRAPH_ROUNDS", "0") == "1"
 
 
 def _ptr(t):
@@ -200,6 +208,12 @@ class Engine:
                           self.rows_device())
         return self._abuf
 
+    def run_rounds(self, native_net, feat_buf, layout, logits_buf, values_buf, graph: bool = True):
+        """All remaining batch rounds of the search in one native call (asynchronous mode; the root must be expanded).
+        graph: replay a captured HIP graph of the rounds' launches when the network allows it."""
+        return N.check(self.L.az_mcts_run_rounds(self._h, native_net._h, _ptr(feat_buf), int(layout), _ptr(logits_buf), _ptr(values_buf),
+                                                 1 if graph else 0, _stream()), "az_mcts_run_rounds") == 1   # True: replayed from the graph
+
     def run_search(self, evaluator, add_noise=False, rngs=None, enable=None, layout=N.AZ_FEAT_F32_NCHW,
                    capture_priors=None, native_net=None):
         """mcts.py:165-225 for all games. `evaluator(features) -> (logits, values)` gets a device tensor in
@@ -232,11 +246,8 @@ class Engine:
             fb, lb, vb, rows_dev = self._async_buffers()
             self.set_async(True)
             try:
-                while not done:
-                    self.search_select()
-                    self.gather(self.max_rows, layout, out=fb)
-                    native_net.forward_indirect(fb, rows_dev, self.max_rows, lb, vb)
-                    done = self.expand(lb, vb)
+                native_net.reserve(self.max_rows)
+                self.run_rounds(native_net, fb, layout, lb, vb, graph=GRAPH_ROUNDS)
                 out = self.result()
                 self.stats()          # reports a failed select / exhausted node pool of the enqueued batches
             finally:

@@ -10,6 +10,7 @@ run(num_games) returns the tuple run_selfplay returns (train.py:395-463):
 from __future__ import annotations
 
 import ctypes as C
+import os
 import random
 import time
 from dataclasses import dataclass
@@ -18,7 +19,9 @@ import numpy as np
 import torch
 
 from . import _native as N
-from .engine import Engine
+from .engine import GRAPH_ROUNDS, Engine
+
+NATIVE_ROUNDS = os.environ.get("AZ_NATIVE_ROUNDS", "1") != "0"   # 0: one call per kernel from Python (A/B timing)
 
 
 @dataclass
@@ -263,6 +266,10 @@ class _Lane:
             done = eng.expand(logits, values, torch.from_numpy(noise))
             c["nn_rows"] += rows
             c["nn_rows_nodedup"] += rows
+            if not done and self.async_search and NATIVE_ROUNDS:   # every remaining round in one native call (a graph replay where possible)
+                if eng.run_rounds(self.net, self.feat_buf, self.layout, self.logits_buf, self.values_buf, graph=self.o.graph_rounds):
+                    c["graph_replays"] += 1
+                done = True
             while not done and self.async_search:
                 eng.search_select()
                 eng.gather(self.max_rows, self.layout, out=self.feat_buf)
@@ -377,13 +384,14 @@ class BatchedSelfPlay:
 
     def __init__(self, model, cfg: SelfPlayConfig, games: int, seed0: int = 0, dedup_leaves: bool = True,
                  precision: str = "bf16", collect_samples: bool = True, device=None, rng_threads: int = 8,
-                 lanes: int = 1, tower_workgroups: int | None = None, reuse_roots: bool = True):
+                 lanes: int = 1, tower_workgroups: int | None = None, reuse_roots: bool = True, graph_rounds: bool | None = None):
         self.cfg, self.G, self.seed0 = cfg, int(games), int(seed0)
+        self.graph_rounds = GRAPH_ROUNDS if graph_rounds is None else bool(graph_rounds)   # replay a move's rounds from a HIP graph
         self.reuse_roots = bool(reuse_roots)
         self.collect = collect_samples
         self.dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         lanes = max(1, min(int(lanes), self.G))
-        self.counters = dict(moves=0, sims=0, nn_rows=0, nn_rows_nodedup=0, games=0, steps=0, depth_sum=0,
+        self.counters = dict(moves=0, sims=0, nn_rows=0, nn_rows_nodedup=0, games=0, steps=0, depth_sum=0, graph_replays=0,
                              t_host_rng=0.0, t_host_policy=0.0, t_samples=0.0)
         share = [self.G // lanes + (1 if i < self.G % lanes else 0) for i in range(lanes)]
         self.lanes = [_Lane(self, i, g, model, precision, dedup_leaves, rng_threads, own_stream=lanes > 1)

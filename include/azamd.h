@@ -117,6 +117,16 @@ int az_mcts_gather_rows(az_engine* e, int32_t* rows_out, void* stream);
  * exit on the device-side row count, so a whole search can be enqueued without host round trips.
  * Failures are then reported by the next az_mcts_pending / az_mcts_stats call. */
 int az_mcts_set_async(az_engine* e, int32_t enable);
+/* All remaining batch rounds of a search in one call (the loop of mcts.py:181-220 once the root is expanded): select,
+ * leaf gather into `feat_dev`, az_net_forward_indirect of `net` into `logits_dev` / `values_dev`, expand + backup, until
+ * the simulations are used up. Needs asynchronous mode and buffers for az_engine_max_rows rows. use_graph != 0: the
+ * launches are captured into a HIP graph the first time and replayed by later calls with the same network and buffers
+ * (a move's rounds always launch with the same arguments, the row counts live on the device); taken only when
+ * az_net_capturable(net, rows) holds and the stream can be captured (not the legacy default stream), otherwise the
+ * rounds are enqueued one by one. Returns 1 when the graph was launched, 0 when the rounds were enqueued, < 0 on error.
+ * Failures of the rounds themselves surface at az_mcts_stats, as in asynchronous mode. */
+int az_mcts_run_rounds(az_engine* e, az_net* net, void* feat_dev, int32_t layout, float* logits_dev, float* values_dev,
+                       int32_t use_graph, void* stream);
 /* Device address of the int32 pending-row count (valid on `stream` after az_mcts_begin/az_mcts_select),
  * for consumers that size their work on the device (az_net_forward_indirect). */
 int az_mcts_rows_device(az_engine* e, const int32_t** rows_dev_out);
@@ -190,6 +200,10 @@ int64_t az_net_static_max_rows(const az_net* net);
  * layer-by-layer network runs one sequence per chunk of the bound, and the sequences past the live rows are empty
  * launches that still cost their dispatch, so a caller may prefer one host round trip per batch when this exceeds 1. */
 int az_net_indirect_passes(const az_net* net, int32_t max_rows);
+
+/* 1 if az_net_forward_indirect over max_rows rows is launches only (one pass, scratch reserved by az_net_reserve, launch
+ * timing off) and may therefore be recorded by a stream capture; 0 otherwise. No upstream counterpart. */
+int az_net_capturable(const az_net* net, int32_t max_rows);
 
 /* Timing of the dominant kernel (the fused tower) with HIP events recorded on the launch stream.
  * If the three output pointers are non-NULL they receive the total milliseconds, launch count and

@@ -145,7 +145,7 @@ def test_lockstep_selfplay_reproduces_upstream_game(name, slots):
     del want_actions
 
 
-def _small_selfplay(lanes, use_async, games=6, num_games=9, steps=None, reuse_roots=True):
+def _small_selfplay(lanes, use_async, games=6, num_games=9, steps=None, reuse_roots=True, graph_rounds=False):
     import torch
     from alphazero_amd.model import AlphaZeroNet
     from alphazero_amd.selfplay import BatchedSelfPlay, SelfPlayConfig
@@ -153,7 +153,7 @@ def _small_selfplay(lanes, use_async, games=6, num_games=9, steps=None, reuse_ro
     net = AlphaZeroNet(board_size=5, channels=32, num_blocks=2).eval().cuda()
     cfg = SelfPlayConfig(board_size=5, mcts_simulations=24, mcts_inference_batch=4, mcts_topk_expand=6)
     sp = BatchedSelfPlay(net, cfg, games=games, seed0=11, lanes=lanes, tower_workgroups=None if lanes == 1 else 1024,
-                         reuse_roots=reuse_roots)
+                         reuse_roots=reuse_roots, graph_rounds=graph_rounds)
     assert sp.async_search
     sp.set_async(use_async)
     assert sp.async_search == use_async
@@ -178,6 +178,22 @@ def test_async_search_equals_synchronous_search():
             assert np.array_equal(xa, xb)
     for k in ("sims", "nn_rows", "nn_rows_nodedup", "depth_sum", "moves"):
         assert a.counters[k] == b.counters[k], k
+
+
+def test_graph_replay_of_a_moves_rounds_plays_the_same_games():
+    """az_mcts_run_rounds with use_graph: the launches of a move's batch rounds are captured once per lane and replayed
+    for every later move; trajectories and counters equal those of the rounds enqueued one by one."""
+    plain = _small_selfplay(2, True, steps=6)
+    graph = _small_selfplay(2, True, steps=6, graph_rounds=True)
+    assert plain.counters["graph_replays"] == 0
+    assert graph.counters["graph_replays"] == 2 * 6          # every move of both lanes, the capturing call included
+    assert len(plain.lanes[0].log) == len(graph.lanes[0].log) == 6
+    for la, lb in zip(plain.lanes, graph.lanes):
+        for ra, rb in zip(la.log, lb.log):
+            for xa, xb in zip(ra, rb):
+                assert np.array_equal(xa, xb)
+    for k in ("sims", "nn_rows", "nn_rows_nodedup", "depth_sum", "moves"):
+        assert plain.counters[k] == graph.counters[k], k
 
 
 @pytest.mark.parametrize("lanes", [2, 3])
