@@ -102,3 +102,34 @@ def test_bf16_feature_layout_matches_f32():
     assert torch.equal(bf[:, :, :21], want.to(torch.bfloat16).float())
     assert (bf[:, :, 21:] == 0).all()
     eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,hist", [(9, 16), (5, 1), (13, 8)])
+def test_bf16_feature_layout_other_plane_counts(n, hist):
+    """The channel-minor bf16 planes for plane counts other than 21: more than 32 planes (history 16: 37 planes padded to
+    64 channels), the minimum (history 1: 7 planes), and a board with several points per lane; root features and the
+    leaf gather of a search both equal the float32 planes, captures included (the capture planes are not 0/1)."""
+    from alphazero_amd import _native as N
+    G = 6
+    eng = _engine(board_size=n, history_len=hist, games=G, num_simulations=8, inference_batch_size=4)
+    rng = np.random.default_rng(n + hist)
+    for _ in range(n * n - n):     # boards nearly full: captures have happened
+        lm = eng.legal_mask().cpu().numpy()
+        acts = [int(rng.choice(np.nonzero(lm[g][:-1])[0])) if lm[g][:-1].any() else n * n for g in range(G)]
+        eng.play(acts)
+    C, cpad, npts = 2 * hist + 5, (32 if 2 * hist + 5 <= 32 else 64), n * n
+    for source in ("root", "leaf"):
+        if source == "root":
+            f32, bf = eng.features().cpu(), eng.features(N.AZ_FEAT_BF16_NHWC).cpu().float()
+        else:
+            eng.search_begin()
+            rows = eng.pending()
+            assert rows == G
+            f32, bf = eng.gather(rows).cpu(), eng.gather(rows, N.AZ_FEAT_BF16_NHWC).cpu().float()
+        assert bf.shape == (G, npts, cpad)
+        want = f32.reshape(G, C, npts).permute(0, 2, 1)
+        assert torch.equal(bf[:, :, :C], want.to(torch.bfloat16).float()), source
+        assert (bf[:, :, C:] == 0).all()
+        assert (want[:, :, 2 * hist + 3:].max() > 0)          # some captures happened
+    eng.close()
