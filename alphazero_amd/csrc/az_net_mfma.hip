@@ -159,6 +159,9 @@ __device__ __forceinline__ void se_gate(f32x4 (&acc)[MI][NI], const char* act, f
     const float* b2 = b1 + hid;
     // Pooling: one thread per (board, channel pair) adds the board's positions in index order, so the
     // pooled value is bit-identical whichever slot of whichever workgroup the board occupies.
+    // (Splitting a board's positions over four lanes with 16-byte reads and a fixed combining tree, and fc2's hidden units
+    // over four lanes likewise, was measured 1-2 % slower end to end in the two-per-CU kernel: these phases run in the
+    // shadow of the compute unit's other workgroup, and the wider versions only add LDS and issue pressure.)
     const float inv_np = 1.0f / (float)NP;
     for (int i = t_; i < nb * (C / 2); i += NT) {
         const int b = i / (C / 2), cp = i - b * (C / 2);

@@ -192,6 +192,29 @@ def test_bf16_small_and_large_batches_agree_bitwise():
             assert torch.equal(lg, lg_all[lo:hi]) and torch.equal(v, v_all[lo:hi]), (kw, lo, hi)
 
 
+def test_bf16_forward_is_deterministic():
+    """The same batch evaluated over and over by the fused tower (two-per-CU kernel, 256-row kernel, and a slice through the
+    96-row kernel) gives the same bits every time, the first launch of a fresh network included: guards against races
+    between the phases of a workgroup that only show under some timings."""
+    import os
+    import stubnets
+    kw = dict(board_size=9, channels=192, num_blocks=3)
+    net = _default_init(kw, seed=8)
+    dev = torch.device("cuda:0")
+    f = _to_nhwc_bf16(stubnets.synthetic_planes(1400, 21, 9, seed=4)).to(dev)
+    nn = net.to(dev).native("bf16", shared=False)
+    os.environ["AZ_TOWER_DUO"] = "0"
+    try:
+        nn256 = net.native("bf16", shared=False)
+    finally:
+        del os.environ["AZ_TOWER_DUO"]
+    ref_lg, ref_v = (t.clone() for t in nn(f))
+    for rep in range(12):
+        for fn, sl in ((nn, slice(0, 1400)), (nn256, slice(0, 1400)), (nn, slice(700, 1100))):
+            lg, v = fn(f[sl].contiguous())
+            assert torch.equal(lg, ref_lg[sl]) and torch.equal(v, ref_v[sl]), (rep, sl)
+
+
 def test_unsupported_bf16_shape_is_refused():
     from alphazero_amd.model import AlphaZeroNet
     from alphazero_amd import _native as N
