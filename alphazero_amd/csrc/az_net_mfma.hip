@@ -522,12 +522,12 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void k_tower(TowerParams P) {
 // RB boards per workgroup so that the linear layer's weights are fetched once per RB boards; every
 // board's sums run in the same order whichever workgroup and slot it is in.
 template <int RB>
-__global__ __launch_bounds__(256) void k_policy_tail(const uint16_t* __restrict__ hq, const float* __restrict__ w3, const float* __restrict__ b3,
-                                                     const float* __restrict__ wfcT, const float* __restrict__ bfc, float* __restrict__ logits,
-                                                     int rows, int np, int q, const int* rows_dev, int row_off) {
+__device__ __forceinline__ void policy_tail_body(int bx, const uint16_t* __restrict__ hq, const float* __restrict__ w3, const float* __restrict__ b3,
+                                                 const float* __restrict__ wfcT, const float* __restrict__ bfc, float* __restrict__ logits,
+                                                 int rows, int np, int q, const int* rows_dev, int row_off) {
     extern __shared__ float flat[];  // [RB][2*np]
     if (rows_dev) rows = min(rows, *rows_dev - row_off);   // this launch covers rows row_off .. of the batch
-    const int r0 = blockIdx.x * RB, A = np + 1, q2 = 2 * q, F = 2 * np;
+    const int r0 = bx * RB, A = np + 1, q2 = 2 * q, F = 2 * np;
     const int nbk = min(RB, rows - r0);
     if (nbk <= 0) return;
     for (int i = threadIdx.x; i < RB * F; i += blockDim.x) {
@@ -578,6 +578,13 @@ __global__ __launch_bounds__(256) void k_policy_tail(const uint16_t* __restrict_
     }
 }
 
+template <int RB>
+__global__ __launch_bounds__(256) void k_policy_tail(const uint16_t* __restrict__ hq, const float* __restrict__ w3, const float* __restrict__ b3,
+                                                     const float* __restrict__ wfcT, const float* __restrict__ bfc, float* __restrict__ logits,
+                                                     int rows, int np, int q, const int* rows_dev, int row_off) {
+    policy_tail_body<RB>(blockIdx.x, hq, w3, b3, wfcT, bfc, logits, rows, np, q, rows_dev, row_off);
+}
+
 // Value tail (model.py:82-86): flatten channel-major, linear + ReLU, linear + tanh. RB boards per block.
 template <int RB>
 __global__ __launch_bounds__(256) void k_value_tail(const uint16_t* __restrict__ hq, const uint16_t* __restrict__ w4T, const float* __restrict__ b4,
@@ -622,18 +629,18 @@ __global__ __launch_bounds__(256) void k_value_tail(const uint16_t* __restrict__
 // activations are stored in); the weights are packed to match (pack_value_fc). value = tanh(w6 . hidden + b6)
 // with a fixed reduction tree, so a board's value does not depend on its row or on the other rows.
 template <int NTW>
-__global__ __launch_bounds__(256) void k_value_tail_mfma(const uint16_t* __restrict__ hq, const uint4* __restrict__ w4p, const float* __restrict__ b4p,
-                                                         const float* __restrict__ w6p, const float* __restrict__ b6, float* __restrict__ values,
-                                                         int rows, int np, int q, int nks, int ntiles, unsigned recip_qc, const int* rows_dev, int row_off, float* part_out, int part_stride) {
+__device__ __forceinline__ void value_tail_body(int bx, int by, const uint16_t* __restrict__ hq, const uint4* __restrict__ w4p, const float* __restrict__ b4p,
+                                                const float* __restrict__ w6p, const float* __restrict__ b6, float* __restrict__ values,
+                                                int rows, int np, int q, int nks, int ntiles, unsigned recip_qc, const int* rows_dev, int row_off, float* part_out, int part_stride) {
     __shared__ float red[4][16];
     if (rows_dev) rows = min(rows, *rows_dev - row_off);
-    const int r0 = blockIdx.x * 16;
+    const int r0 = bx * 16;
     if (r0 >= rows) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, kq = lane >> 4;
     const int row = min(r0 + li, rows - 1);
     const int qc = q >> 3, nfrag = np * qc;
     const uint16_t* abase = hq + (size_t)row * np * 2 * q + q;   // the value half of this board's head activations
-    const int t0 = blockIdx.y * NTW;                             // split launch: this workgroup's share of the unit tiles
+    const int t0 = by * NTW;                                     // split launch: this workgroup's share of the unit tiles
     const uint4* bbase = w4p + (size_t)wave * 64 + lane + (size_t)t0 * 256;   // tile `wave + 4 t0` of k-step 0; tiles wave + 4(t0 + t) follow at +256t vectors
     const size_t kstride = (size_t)ntiles * 64;
     const uint4 zero4 = make_uint4(0, 0, 0, 0);
@@ -700,9 +707,33 @@ __global__ __launch_bounds__(256) void k_value_tail_mfma(const uint16_t* __restr
     if (threadIdx.x < 16 && r0 + (int)threadIdx.x < rows) {
         const int i = threadIdx.x;
         const float sum = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
-        if (part_out) part_out[(size_t)(r0 + i) * part_stride + blockIdx.y] = sum;   // split launch: k_value_finish adds the shares
+        if (part_out) part_out[(size_t)(r0 + i) * part_stride + by] = sum;   // split launch: k_value_finish adds the shares
         else values[r0 + i] = tanhf(sum + b6[0]);
     }
+}
+
+template <int NTW>
+__global__ __launch_bounds__(256) void k_value_tail_mfma(const uint16_t* __restrict__ hq, const uint4* __restrict__ w4p, const float* __restrict__ b4p,
+                                                         const float* __restrict__ w6p, const float* __restrict__ b6, float* __restrict__ values,
+                                                         int rows, int np, int q, int nks, int ntiles, unsigned recip_qc, const int* rows_dev, int row_off, float* part_out, int part_stride) {
+    value_tail_body<NTW>(blockIdx.x, blockIdx.y, hq, w4p, b4p, w6p, b6, values, rows, np, q, nks, ntiles, recip_qc, rows_dev, row_off, part_out, part_stride);
+}
+
+// Both tails in one launch (boards up to 9x9, un-split value tail): workgroups 0 .. n_policy-1 are the policy tail's, the rest
+// the value tail's. The two read the same head activations and are independent, so they share the machine instead of running
+// one after the other; each computes exactly what its own kernel computes.
+struct TailArgs {
+    const uint16_t* hq; const float *w3, *b3, *wfcT, *bfc; float* logits;
+    const uint4* w4p; const float *b4p, *w6p, *b6; float* values;
+    int rows, np, q, nks, ntiles; unsigned recip_qc; const int* rows_dev; int row_off, n_policy;
+};
+template <int NTW>
+__global__ __launch_bounds__(256) void k_tails(TailArgs a) {
+    if ((int)blockIdx.x < a.n_policy)
+        policy_tail_body<8>(blockIdx.x, a.hq, a.w3, a.b3, a.wfcT, a.bfc, a.logits, a.rows, a.np, a.q, a.rows_dev, a.row_off);
+    else
+        value_tail_body<NTW>(blockIdx.x - a.n_policy, 0, a.hq, a.w4p, a.b4p, a.w6p, a.b6, a.values, a.rows, a.np, a.q, a.nks, a.ntiles, a.recip_qc,
+                             a.rows_dev, a.row_off, nullptr, 0);
 }
 
 // Second half of a split value tail: value = tanh(sum of the workgroups' shares in index order + b6).
@@ -1088,6 +1119,19 @@ static void run_tails(MfmaNet* m, const uint16_t* hq_in, int rows, const int* ro
     const int np = c.board_size * c.board_size, q = m->q;
     // boards per workgroup by board size only (a board's sums run in the same order either way): large boards come in
     // chunks of a few hundred rows, which 8 per workgroup would spread over too few CUs
+    if (np <= 81 && m->w4p && !(m->vpart && (m->v_ntiles + 3) / 4 > 1)) {   // both tails in one launch
+        TailArgs a{hq_in, m->w3, m->b3, m->wfcT, m->bfc, logits, (const uint4*)m->w4p, m->b4p, m->w6p, m->b6, values,
+                   rows, np, q, m->v_nks, m->v_ntiles, m->v_recip, rows_dev, row_off, (rows + 7) / 8};
+        const dim3 grid(a.n_policy + (rows + 15) / 16);
+        const size_t lds = (size_t)8 * 2 * np * 4;
+        switch ((m->v_ntiles + 3) / 4) {
+            case 1: hipLaunchKernelGGL((k_tails<1>), grid, dim3(256), lds, st, a); break;
+            case 2: hipLaunchKernelGGL((k_tails<2>), grid, dim3(256), lds, st, a); break;
+            case 3: hipLaunchKernelGGL((k_tails<3>), grid, dim3(256), lds, st, a); break;
+            default: hipLaunchKernelGGL((k_tails<4>), grid, dim3(256), lds, st, a); break;
+        }
+        return;
+    }
     if (np <= 81)
         hipLaunchKernelGGL((k_policy_tail<8>), dim3((rows + 7) / 8), dim3(256), (size_t)8 * 2 * np * 4, st, hq_in, m->w3, m->b3, m->wfcT, m->bfc, logits, rows,
                            np, q, rows_dev, row_off);
