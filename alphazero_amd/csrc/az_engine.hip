@@ -524,7 +524,7 @@ __device__ inline void wave_argmax(double& s, int& idx) {
 
 // mcts.py:181-199: batch_n descents for game blockIdx.x.
 template <int PPL>
-__global__ __launch_bounds__(64) void k_select(Dev d, int batch_n) {
+__device__ __forceinline__ void select_body(const Dev& d, int batch_n) {
     __shared__ BoardLds<PPL> b;
     __shared__ int8_t root_col[BoardLds<PPL>::NPAD];
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
@@ -703,6 +703,9 @@ __global__ __launch_bounds__(64) void k_select(Dev d, int batch_n) {
         gs[ST_ROWS] += n_unique;
     }
 }
+
+template <int PPL>
+__global__ __launch_bounds__(64) void k_select(Dev d, int batch_n) { select_body<PPL>(d, batch_n); }
 
 // Leaf gather: one wave per pending row replays the row's path from its game's root and writes the
 // feature planes (dense, row order) and the legal mask.
@@ -945,8 +948,7 @@ __global__ __launch_bounds__(64) void k_expand_root(Dev d, const float* logits, 
 }
 
 // Expand the batch's leaves, then revert virtual loss and back up in slot order (mcts.py:203-218).
-__global__ __launch_bounds__(64) void k_expand_backup(Dev d, const float* logits, const float* values, int batch_n,
-                                                      double* priors_out) {
+__device__ __forceinline__ void expand_backup_body(const Dev& d, const float* logits, const float* values, int batch_n, double* priors_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
     double* p_lds = (double*)dyn;
     double* s_val = p_lds + 2 * d.A;          // [B] value each slot backs up
@@ -1035,6 +1037,21 @@ __global__ __launch_bounds__(64) void k_expand_backup(Dev d, const float* logits
         if (lane < rnc) { visits[rfirst + lane] = c_vis; vsum[rfirst + lane] = c_vsum; }
         if (lane == 0) { visits[0] = r_vis; vsum[0] = r_vsum; }
     }
+}
+
+__global__ __launch_bounds__(64) void k_expand_backup(Dev d, const float* logits, const float* values, int batch_n, double* priors_out) {
+    expand_backup_body(d, logits, values, batch_n, priors_out);
+}
+
+// Expansion + backup of one batch followed by the descents of the next, for the same game in the same wave: between the
+// two nothing crosses games (the row scan, the leaf gather and the network sit between a select and its expand), so a
+// search enqueued as a whole saves one launch and one kernel start-up per round.
+template <int PPL>
+__global__ __launch_bounds__(64) void k_expand_select(Dev d, const float* logits, const float* values, int batch_prev, double* priors_out, int batch_next) {
+    expand_backup_body(d, logits, values, batch_prev, priors_out);
+    __threadfence_block();
+    __syncthreads();   // the statistics written by the backup are read by the descents
+    select_body<PPL>(d, batch_next);
 }
 
 __global__ __launch_bounds__(64) void k_root_counts(Dev d, int* counts) {
@@ -1292,11 +1309,16 @@ int az_mcts_begin(az_engine* e, const uint8_t* enable, void* stream) {
     return check_launch("k_begin");
 }
 
+// dynamic LDS of the descents: seen keys, then path, uniq pairs, staged len / ref / path[8], terminal-leaf cache (node, value)
+static size_t select_shmem(const az_engine* e) {
+    return seen_bytes(e) + ((size_t)e->d.max_depth + (2 + 2 + 8 + 1 + 2) * (size_t)e->d.B) * 4;
+}
+
 int az_mcts_select(az_engine* e, void* stream) {
     if (!e) return fail(AZ_ERR_ARG, "null engine");
     if (e->phase != PH_NEED_SELECT) return fail(AZ_ERR_STATE, "az_mcts_select: no batch to select (expand the pending rows first)");
     e->batch_n = std::min(e->d.B, e->d.sims - e->sims_done);
-    DISPATCH_PPL(e, k_select, e->d.G, seen_bytes(e) + ((size_t)e->d.max_depth + (2 + 2 + 8 + 1 + 2) * (size_t)e->d.B) * 4, stream, e->d, e->batch_n);   // path, uniq pairs, staged len / ref / path[8], terminal-leaf cache (node, value)
+    DISPATCH_PPL(e, k_select, e->d.G, select_shmem(e), stream, e->d, e->batch_n);
     hipLaunchKernelGGL(k_scan_rows, dim3(1), dim3(1024), 0, (hipStream_t)stream, e->d, 0);
     e->phase = PH_SELECTED;
     e->rows_known = false;
@@ -1424,16 +1446,30 @@ int az_mcts_expand(az_engine* e, const float* logits, const float* values, const
 // Enqueue the batch rounds from the engine's state (az_mcts_select .. az_mcts_expand until the simulations are used up).
 static int enqueue_rounds(az_engine* e, az_net* net, void* feat, int32_t layout, float* logits, float* values, void* stream) {
     const int32_t max_rows = std::max(e->d.max_rows, e->d.G);
+    int rc = az_mcts_select(e, stream);
+    if (rc != AZ_OK) return rc;
     for (;;) {
-        int rc = az_mcts_select(e, stream);
-        if (rc != AZ_OK) return rc;
         rc = az_mcts_gather(e, feat, layout, stream);
         if (rc != AZ_OK) return rc;
         rc = az_net_forward_indirect(net, feat, e->d.ctl, max_rows, logits, values, stream);
         if (rc != AZ_OK) return rc;
-        rc = az_mcts_expand(e, logits, values, nullptr, stream);
-        if (rc < 0) return rc;
-        if (rc == 1) return AZ_OK;
+        const int left = e->d.sims - (e->sims_done + e->batch_n);
+        if (left <= 0) {   // the last batch: expansion and backup only
+            rc = az_mcts_expand(e, logits, values, nullptr, stream);
+            return rc < 0 ? rc : AZ_OK;
+        }
+        // expansion + backup of this batch and the descents of the next in one launch, then the row scan
+        const int batch_next = std::min(e->d.B, left);
+        const size_t shmem = std::max((size_t)e->d.A * 16 + (size_t)e->d.B * 16 + 64, select_shmem(e));
+        DISPATCH_PPL(e, k_expand_select, e->d.G, shmem, stream, e->d, (const float*)logits, (const float*)values, e->batch_n, e->last_priors, batch_next);
+        hipLaunchKernelGGL(k_scan_rows, dim3(1), dim3(1024), 0, (hipStream_t)stream, e->d, 0);
+        rc = check_launch("k_expand_select");
+        if (rc != AZ_OK) return rc;
+        e->sims_done += e->batch_n;
+        e->batch_n = batch_next;
+        e->phase = PH_SELECTED;
+        e->rows_known = false;
+        e->last_rows = -1;
     }
 }
 
