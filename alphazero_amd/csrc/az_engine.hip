@@ -427,9 +427,33 @@ __global__ __launch_bounds__(64) void k_begin(Dev d, const uint8_t* enable) {
     }
 }
 
-// Exclusive scan of n_unique over games -> row offsets, row->(game, slot) tables, row count.
+// Exclusive scan of n_unique over games -> row offsets, row->(game, slot) tables, row count. One workgroup of 16 waves:
+// a thread sums its share of consecutive games, a wave scans its 64 sums by lane shifts, the 16 wave totals are scanned by
+// every thread from LDS (two barriers in all).
+__device__ inline int block_exclusive_scan_1024(int v, int* wave_tot, int& total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(inc, o);
+        if (lane >= o) inc += up;
+    }
+    __syncthreads();                 // a previous use of wave_tot has been read
+    if (lane == 63) wave_tot[wave] = inc;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        const int t = wave_tot[w];
+        if (w < wave) base += t;
+        tot += t;
+    }
+    total = tot;
+    return base + inc - v;
+}
+
 __global__ __launch_bounds__(1024) void k_scan_rows(Dev d, int root_phase) {
-    __shared__ int part[1024];
+    __shared__ int wave_tot[16];
     const int t = threadIdx.x;
     const int per = (d.G + 1023) / 1024;
     const int lo = min(t * per, d.G), hi = min(lo + per, d.G);
@@ -439,16 +463,8 @@ __global__ __launch_bounds__(1024) void k_scan_rows(Dev d, int root_phase) {
         if (split && d.root_cached[g]) late += d.n_unique[g];
         else sum += d.n_unique[g];
     }
-    part[t] = sum;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-        int v = t >= o ? part[t - o] : 0;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
-    }
-    int off = part[t] - sum;
-    const int n_eval = part[1023];
+    int n_eval;
+    int off = block_exclusive_scan_1024(sum, wave_tot, n_eval);
     for (int g = lo; g < hi; ++g) {
         if (split && d.root_cached[g]) continue;
         d.row_off[g] = off;
@@ -461,23 +477,15 @@ __global__ __launch_bounds__(1024) void k_scan_rows(Dev d, int root_phase) {
     }
     int n_all = n_eval;
     if (split) {
-        __syncthreads();
-        part[t] = late;
-        __syncthreads();
-        for (int o = 1; o < 1024; o <<= 1) {
-            int v = t >= o ? part[t - o] : 0;
-            __syncthreads();
-            part[t] += v;
-            __syncthreads();
-        }
-        off = n_eval + part[t] - late;
+        int n_late;
+        off = n_eval + block_exclusive_scan_1024(late, wave_tot, n_late);
         for (int g = lo; g < hi; ++g) {
             if (!d.root_cached[g]) continue;
             d.row_off[g] = off;
             for (int u = 0; u < d.n_unique[g]; ++u) { d.row_game[off + u] = g; d.row_slot[off + u] = -1; }
             off += d.n_unique[g];
         }
-        n_all = n_eval + part[1023];
+        n_all = n_eval + n_late;
     }
     if (t == 1023) { d.row_off[d.G] = n_all; d.ctl[0] = n_eval; d.ctl[2] = n_all; }
 }
