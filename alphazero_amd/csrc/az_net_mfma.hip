@@ -719,20 +719,22 @@ __global__ __launch_bounds__(256) void k_value_tail_mfma(const uint16_t* __restr
     value_tail_body<NTW>(blockIdx.x, blockIdx.y, hq, w4p, b4p, w6p, b6, values, rows, np, q, nks, ntiles, recip_qc, rows_dev, row_off, part_out, part_stride);
 }
 
-// Both tails in one launch (boards up to 9x9, un-split value tail): workgroups 0 .. n_policy-1 are the policy tail's, the rest
-// the value tail's. The two read the same head activations and are independent, so they share the machine instead of running
+// Both tails in one launch (boards up to 9x9, un-split value tail). The two read the same head activations and are independent, so they share the machine instead of running
 // one after the other; each computes exactly what its own kernel computes.
 struct TailArgs {
     const uint16_t* hq; const float *w3, *b3, *wfcT, *bfc; float* logits;
     const uint4* w4p; const float *b4p, *w6p, *b6; float* values;
-    int rows, np, q, nks, ntiles; unsigned recip_qc; const int* rows_dev; int row_off, n_policy;
+    int rows, np, q, nks, ntiles; unsigned recip_qc; const int* rows_dev; int row_off;
 };
 template <int NTW>
 __global__ __launch_bounds__(256) void k_tails(TailArgs a) {
-    if ((int)blockIdx.x < a.n_policy)
-        policy_tail_body<8>(blockIdx.x, a.hq, a.w3, a.b3, a.wfcT, a.bfc, a.logits, a.rows, a.np, a.q, a.rows_dev, a.row_off);
+    // workgroups come in threes per 16 boards - two policy workgroups (8 boards each) and one value workgroup - so that
+    // the live workgroups of both kinds are dispatched first when the grid covers an upper bound of the row count
+    const int unit = blockIdx.x / 3, role = blockIdx.x - 3 * unit;
+    if (role < 2)
+        policy_tail_body<8>(2 * unit + role, a.hq, a.w3, a.b3, a.wfcT, a.bfc, a.logits, a.rows, a.np, a.q, a.rows_dev, a.row_off);
     else
-        value_tail_body<NTW>(blockIdx.x - a.n_policy, 0, a.hq, a.w4p, a.b4p, a.w6p, a.b6, a.values, a.rows, a.np, a.q, a.nks, a.ntiles, a.recip_qc,
+        value_tail_body<NTW>(unit, 0, a.hq, a.w4p, a.b4p, a.w6p, a.b6, a.values, a.rows, a.np, a.q, a.nks, a.ntiles, a.recip_qc,
                              a.rows_dev, a.row_off, nullptr, 0);
 }
 
@@ -1121,8 +1123,8 @@ static void run_tails(MfmaNet* m, const uint16_t* hq_in, int rows, const int* ro
     // chunks of a few hundred rows, which 8 per workgroup would spread over too few CUs
     if (np <= 81 && m->w4p && !(m->vpart && (m->v_ntiles + 3) / 4 > 1)) {   // both tails in one launch
         TailArgs a{hq_in, m->w3, m->b3, m->wfcT, m->bfc, logits, (const uint4*)m->w4p, m->b4p, m->w6p, m->b6, values,
-                   rows, np, q, m->v_nks, m->v_ntiles, m->v_recip, rows_dev, row_off, (rows + 7) / 8};
-        const dim3 grid(a.n_policy + (rows + 15) / 16);
+                   rows, np, q, m->v_nks, m->v_ntiles, m->v_recip, rows_dev, row_off};
+        const dim3 grid(3 * ((rows + 15) / 16));
         const size_t lds = (size_t)8 * 2 * np * 4;
         switch ((m->v_ntiles + 3) / 4) {
             case 1: hipLaunchKernelGGL((k_tails<1>), grid, dim3(256), lds, st, a); break;
