@@ -356,6 +356,7 @@ def main():
         "nn_rows_per_s": round(rows / dt_max, 1),
         "nn_rows_per_s_if_every_leaf_evaluated": round(rows_raw / dt_max, 1),
         "moves_per_s": round(moves / dt_max, 1),
+        "games_finished_in_window": int(games),   # slots refill as games end; meaningful over windows of a game length or more (--steps 300)
         "mean_leaf_depth": round(depth_sum / max(1.0, sims), 3),
         "roofline": {"bound": "mfma", "kernel": ("k_tower<192,1,4,96,2,176> (two 256-thread workgroups per CU)" if headline else f"k_tower<{wl['ch']},...>") if fused else
                      "layer-by-layer network (k_conv3_slab + gate / residual / tail kernels), timed as one sequence", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS,
