@@ -1363,6 +1363,8 @@ int az_mcts_set_root_reuse(az_engine* e, int32_t enable) {
     Dev& d = e->d;
     HIP_TRY(hipSetDevice(e->cfg.device));
     HIP_TRY(hipDeviceSynchronize());
+    // kernels take the device struct by value: a graph captured with the old one must not be replayed
+    if (e->rounds_exec) { (void)hipGraphExecDestroy(e->rounds_exec); e->rounds_exec = nullptr; }
     if (!enable) { d.rc_cap = 0; return AZ_OK; }
     const int cap = d.K > 0 ? std::min(d.K, d.A) : d.A;
     if ((size_t)d.G * cap * d.A * 4 > ((size_t)1 << 30)) return fail(AZ_ERR_CAPACITY, "root reuse: logits store above 1 GiB");
