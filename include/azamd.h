@@ -124,7 +124,9 @@ int az_mcts_set_async(az_engine* e, int32_t enable);
  * (a move's rounds always launch with the same arguments, the row counts live on the device); taken only when
  * az_net_capturable(net, rows) holds and the stream can be captured (not the legacy default stream), otherwise the
  * rounds are enqueued one by one. Returns 1 when the graph was launched, 0 when the rounds were enqueued, < 0 on error.
- * Failures of the rounds themselves surface at az_mcts_stats, as in asynchronous mode. */
+ * Failures of the rounds themselves surface at az_mcts_stats, as in asynchronous mode. A captured graph refers to the
+ * network's weights and scratch buffers: keep the network alive as long as the engine may replay it (az_engine_destroy and
+ * az_mcts_set_root_reuse drop the graph). */
 int az_mcts_run_rounds(az_engine* e, az_net* net, void* feat_dev, int32_t layout, float* logits_dev, float* values_dev,
                        int32_t use_graph, void* stream);
 /* Device address of the int32 pending-row count (valid on `stream` after az_mcts_begin/az_mcts_select),
