@@ -196,6 +196,47 @@ def test_graph_replay_of_a_moves_rounds_plays_the_same_games():
         assert plain.counters[k] == graph.counters[k], k
 
 
+def test_run_rounds_contract():
+    """az_mcts_run_rounds: refused outside asynchronous mode and before the root is expanded; az_net_capturable is false while
+    launch timing is on or the scratch is not reserved, and then the rounds are enqueued one by one (return value 0)."""
+    import torch
+    from alphazero_amd import _native as N
+    from alphazero_amd.engine import Engine
+    from alphazero_amd.model import AlphaZeroNet
+    torch.manual_seed(1)
+    net = AlphaZeroNet(board_size=5, channels=32, num_blocks=1).eval().cuda()
+    nn = net.native("bf16", shared=False)
+    eng = Engine(board_size=5, games=4, num_simulations=8, inference_batch_size=4, topk_expand=6)
+    L = nn.L
+    feat = torch.zeros((eng.max_rows, 25, 32), dtype=torch.bfloat16, device="cuda")
+    lg = torch.zeros((eng.max_rows, 26), dtype=torch.float32, device="cuda")
+    v = torch.zeros((eng.max_rows,), dtype=torch.float32, device="cuda")
+    assert L.az_net_capturable(nn._h, eng.max_rows) == 0          # nothing reserved yet
+    nn.reserve(eng.max_rows)
+    assert L.az_net_capturable(nn._h, eng.max_rows) == 1
+    nn.profile(True)
+    assert L.az_net_capturable(nn._h, eng.max_rows) == 0          # launch timing records events per launch
+    nn.profile(False)
+    eng.search_begin()
+    with pytest.raises(N.NativeError):                             # not in asynchronous mode
+        eng.run_rounds(nn, feat, N.AZ_FEAT_BF16_NHWC, lg, v)
+    eng.set_async(True)
+    with pytest.raises(N.NativeError):                             # the root rows are still pending
+        eng.run_rounds(nn, feat, N.AZ_FEAT_BF16_NHWC, lg, v)
+    rows = eng.pending()
+    f0 = eng.gather(rows, N.AZ_FEAT_BF16_NHWC)
+    l0, v0 = nn(f0)
+    assert not eng.expand(l0, v0)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        s.wait_stream(torch.cuda.default_stream())
+        assert eng.run_rounds(nn, feat, N.AZ_FEAT_BF16_NHWC, lg, v, graph=False) is False
+        visits, _ = eng.result()
+        st = eng.stats()
+    assert st["sims"] == 4 * 8 and int(visits.sum()) == 4 * 8
+    eng.close()
+
+
 @pytest.mark.parametrize("lanes", [2, 3])
 def test_pipelined_lanes_play_the_same_games(lanes):
     """Games depend on their id only: splitting the slots over lanes that run on their own streams, with
