@@ -880,6 +880,42 @@ __device__ inline void expand_node(const Dev& d, int g, int lane, int node, cons
             pos[k] = lg_[k] ? base + __popcll(bal & ((1ull << lane) - 1ull)) : -1;
             base += __popcll(bal);
         }
+    } else if (A > 128) {
+        // Large action sets (13x13, 19x19): the K kept children are extracted one by one, best first - K wave arg-max
+        // rounds over each lane's best remaining action (prior desc, action asc: the arg-max returns the smallest index
+        // among equal maxima), round r giving slot r. O(K * PPA) per lane instead of O(A * PPA) for counting ranks.
+        unsigned taken = 0;
+        bool pass_in = false;
+        int last_idx = -1;
+#pragma unroll
+        for (int k = 0; k < PPA; ++k) pos[k] = -1;
+        for (int r = 0; r < cnt; ++r) {
+            double best = -INFINITY;
+            int bi = 0x7fffffff;
+#pragma unroll
+            for (int k = 0; k < PPA; ++k)
+                if (lg_[k] && !((taken >> k) & 1u) && pr[k] > best) { best = pr[k]; bi = lane + 64 * k; }
+            wave_argmax(best, bi);          // bi: the action extracted in this round (wave-uniform)
+            if (bi == 0x7fffffff) break;    // cannot happen: nl > K legal actions remain
+            if ((bi & 63) == lane) {
+                const int k = bi >> 6;
+#pragma unroll
+                for (int kk = 0; kk < PPA; ++kk)
+                    if (kk == k) { pos[kk] = r; taken |= 1u << kk; }
+            }
+            pass_in |= bi == A - 1;
+            last_idx = bi;
+        }
+        // the pass (action A-1) is forced in: if it was not among the K extracted it takes the last slot and the action
+        // extracted last is dropped
+        if (!pass_in) {
+#pragma unroll
+            for (int k = 0; k < PPA; ++k) {
+                const int a = lane + 64 * k;
+                if (a == last_idx) pos[k] = -1;
+                if (a == A - 1 && lg_[k]) pos[k] = cnt - 1;
+            }
+        }
     } else {
         // ranking keys: the prior of a legal action, -1 for an illegal one (priors are >= 0, so those never count)
         __syncthreads();
