@@ -15,6 +15,8 @@ os.environ["AZ_TOWER_DUO"] = "0"
 nn256 = net.native("bf16", shared=False)
 del os.environ["AZ_TOWER_DUO"]
 f = T._to_nhwc_bf16(x).to(dev)
+if os.environ.get("AZ_LOOP_GRID"):   # limit the resident workgroups (one per compute unit: 128 for the two-per-CU kernel)
+    nn.set_tower_workgroups(int(os.environ["AZ_LOOP_GRID"]))
 ref_lg, ref_v = nn(f); ref_lg, ref_v = ref_lg.clone(), ref_v.clone()
 bad = 0
 for r in range(reps):
