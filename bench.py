@@ -214,6 +214,58 @@ def kernel_census(net, batch, games, plies=24):
     return out, {"games": games, "root_plies": plies, "mean_leaf_depth": round(depth, 3), "rounds": n_rounds}
 
 
+class PowerWatch:
+    """Socket power and XCD clocks of the card (amd-smi, a sample every ~0.25 s from a side thread) while the timed window runs;
+    silent when the tool is missing or refuses. The figures say whether the run sits at the card's power limit."""
+
+    def __init__(self, gpu):
+        import threading
+        self.gpu, self.samples, self.stop = int(gpu), [], False
+        self.t0 = self.t1 = None            # the timed steps (set by the window)
+        self.thread = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        while not self.stop:
+            try:
+                out = subprocess.run(["amd-smi", "metric", "-g", str(self.gpu), "-p", "-c"], capture_output=True, text=True, timeout=5).stdout
+            except Exception:
+                return
+            power = [ln.split()[1] for ln in out.splitlines() if "SOCKET_POWER" in ln]
+            clocks, in_gfx = [], False
+            for ln in out.splitlines():
+                if "GFX_" in ln and ln.strip().endswith(":"):
+                    in_gfx = True
+                elif in_gfx and " CLK:" in ln:
+                    try:
+                        clocks.append(int(ln.split()[1]))
+                    except ValueError:
+                        pass
+                    in_gfx = False
+            try:
+                if power:
+                    self.samples.append((float(power[0]), clocks[:8], time.perf_counter()))
+            except ValueError:
+                pass
+            time.sleep(0.25)
+
+    def __enter__(self):
+        self.thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.stop = True
+        self.thread.join(timeout=6)
+
+    def summary(self):
+        s = [x for x in self.samples if x[0] > 0 and (self.t0 is None or self.t0 <= x[2] <= (self.t1 or x[2]))]
+        if not s:
+            return None
+        clk = [c for _, cs, _ in s for c in cs]
+        return {"samples": len(s), "socket_power_W": [round(min(x[0] for x in s)), round(max(x[0] for x in s))],
+                "xcd_clock_MHz": [min(clk), max(clk)] if clk else None,
+                "note": "amd-smi metric -p -c sampled during the timed steps; the card's power cap is 1400 W"}
+
+
 def free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -299,7 +351,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def window(sp, steps, warmup, setup=2):
+    def window(sp, steps, warmup, setup=2, watch=None):
         sp.begin(num_games=10 ** 9)          # slots refill for as long as the run lasts
         for _ in range(setup + warmup):      # `setup` steps before the W warm-up steps: first-use allocations of torch's
             sp.step()                        # allocator pools and filling the lane pipeline
@@ -312,11 +364,14 @@ def main():
             sp.step()
         barrier()
         dt = time.perf_counter() - t0
+        if watch is not None:
+            watch.t0, watch.t1 = t0, t0 + dt
         return dt, sp.profile(False, read=True)
 
     sp = BatchedSelfPlay(net, cfg, games=a.games, seed0=1 + rank * a.games, dedup_leaves=not a.no_dedup, lanes=a.lanes,
                          tower_workgroups=twg)
-    dt, (tower_ms_sum, launches, tower_ms) = window(sp, a.steps, a.warmup)   # tower_ms: merged (overlap counted once)
+    with PowerWatch(local) as pw:
+        dt, (tower_ms_sum, launches, tower_ms) = window(sp, a.steps, a.warmup, watch=pw)   # tower_ms: merged (overlap counted once)
 
     c = dict(sp.counters)
     mine = torch.tensor([dt, c["sims"], c["nn_rows"], c["nn_rows_nodedup"], c["moves"], c["games"], c["depth_sum"]],
@@ -376,6 +431,8 @@ def main():
                      "tower_share_of_wall": round(tower_ms * 1e-3 / dt, 4)},
         "host_seconds": {"rng": round(c["t_host_rng"], 4), "policy": round(c["t_host_policy"], 4), "samples": round(c["t_samples"], 4)},
     }
+    if pw.summary():
+        out["power"] = pw.summary()
     del sp
     if not a.no_side_legs and headline:
         # games/hour: moves/s of the timed window over the plies a finished game takes, measured on whole games of the same
