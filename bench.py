@@ -223,6 +223,8 @@ class PowerWatch:
         self.gpu, self.samples, self.stop = int(gpu), [], False
         self.t0 = self.t1 = None            # the timed steps (set by the window)
         self.thread = threading.Thread(target=self._run, daemon=True)
+        # not under a profiler (its preloaded library would ride along into every amd-smi child process)
+        self.enabled = not any(k.startswith("ROCPROF") for k in os.environ) and "rocprof" not in os.environ.get("LD_PRELOAD", "")
 
     def _run(self):
         while not self.stop:
@@ -249,12 +251,14 @@ class PowerWatch:
             time.sleep(0.25)
 
     def __enter__(self):
-        self.thread.start()
+        if self.enabled:
+            self.thread.start()
         return self
 
     def __exit__(self, *exc):
         self.stop = True
-        self.thread.join(timeout=6)
+        if self.enabled:
+            self.thread.join(timeout=6)
 
     def summary(self):
         s = [x for x in self.samples if x[0] > 0 and (self.t0 is None or self.t0 <= x[2] <= (self.t1 or x[2]))]
