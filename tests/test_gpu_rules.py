@@ -42,7 +42,8 @@ def test_rules_trajectory_vs_golden(name, rec):
     eng.close()
 
 
-@pytest.mark.parametrize("n,games,seed", [(5, 96, 1), (9, 128, 2), (13, 32, 3), (19, 16, 4)])
+@pytest.mark.parametrize("n,games,seed", [(5, 96, 1), (9, 128, 2), (13, 32, 3), (19, 16, 4),
+                                          (8, 48, 5), (11, 32, 6), (2, 16, 7)])
 def test_lockstep_random_games_vs_oracle(oracle_lib, n, games, seed):
     """G games in lockstep, each following its own random legal line; every ply every game is compared
     with the oracle (board, scalars, legal mask, feature planes, score)."""

@@ -44,7 +44,8 @@ def test_search_vs_golden(c, dedup):
 
 
 @pytest.mark.parametrize("n,kind,sims,B,K,noise", [(9, "hash", 64, 8, 48, True), (9, "flatish", 48, 16, 0, True),
-                                                    (5, "sharp", 40, 4, 0, False), (13, "hash", 24, 4, 20, True)])
+                                                    (5, "sharp", 40, 4, 0, False), (13, "hash", 24, 4, 20, True),
+                                                    (8, "hash", 32, 8, 0, True), (11, "flatish", 24, 4, 30, True)])
 def test_lockstep_search_vs_oracle(oracle_lib, n, kind, sims, B, K, noise):
     """Many games with different roots searched in lockstep; each game's visits, root value and root
     priors must equal the oracle's search of the same root."""
