@@ -252,6 +252,169 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_conv3_slab(Conv
     }
 }
 
+// The 3x3 convolution for C output channels as 256-thread workgroups, two per compute unit: 128 rows x all C output
+// channels each (4 waves = 4 channel quarters, every wave owns all 128 rows: 8 x C/64 accumulator tiles), so that one
+// workgroup's barriers, slab refills and epilogue run under the other's MFMAs. The activations go through the same
+// 64-channel slabs as in k_conv3_slab (the workgroup's rows + a halo of n+1 rows either side, double-buffered, a zero
+// region behind each slab); the weight fragments come straight from the packed global image (fragment order, chunk-major:
+// one coalesced 1 KiB load per fragment, two k-steps ahead), so LDS serves activation fragments only: 8 KiB of LDS reads
+// per 32 MFMAs and wave, half of what the 64 x 64 wave tiles with LDS-staged weights of k_conv3_slab need. Where a row
+// tile's fragments of a tap start comes from a table in LDS built once per workgroup (offset / 16 of the tap's source row
+// in the slab, or of the bank-preserving spot in the zero region when the tap falls off the board). K order and hence
+// every output bit equal k_conv3_slab's.
+constexpr int kDuoRows = 128, kDuoSlabRows = kDuoRows + 2 * kMaxHalo, kDuoSlabData = kDuoSlabRows * kSlabStride;
+constexpr int kDuoSlabBytes = kDuoSlabData + 512;                 // + zero region (kDuoSlabData is a multiple of 256)
+constexpr int kDuoPieces = (kDuoSlabRows * 8 + 255) / 256;       // 16-byte slab pieces per thread
+#ifndef AZ_DUO_NB
+#define AZ_DUO_NB 2   // weight fragment sets in the ring: the k-step in use + (AZ_DUO_NB - 1) in flight
+#endif
+constexpr int kDuoLds = 2 * kDuoSlabBytes + 9 * kDuoRows * 2;
+static_assert(kDuoSlabData % 256 == 0 && kDuoPieces <= 8, "zero region alignment; one slab piece per tap is staged");
+
+// Waits for this wave's LDS traffic only (the weight fragments in flight stay in flight), then the workgroup barrier.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int C>
+__global__ __launch_bounds__(256, 2) void k_conv3_duo(ConvArgs a) {
+    constexpr int MI = kDuoRows / 16, NI = C / 64, WN = 4, NT = 256, KPT = 2, AR = 4, NF = KPT * MI, NB = AZ_DUO_NB, KS = 9 * KPT;
+    static_assert(NI % 2 == 0 && NF % AR == 0 && KS % NB == 0, "tile pairs; static ring indices across taps and chunks");
+    extern __shared__ __attribute__((aligned(256))) char smem[];
+    char* slab = smem;
+    uint16_t* taptab = (uint16_t*)(smem + 2 * kDuoSlabBytes);
+    AZ_LANE_GEO(MI, NI, WN);
+    a.rows = live_rows(a.rows, a.np, a.rows_dev, a.board_off);
+    const int n = a.n, np = a.np, halo = n + 1, srows = kDuoRows + 2 * halo;
+    // consecutive row tiles share halo rows: give them to one XCD (workgroup ids are dealt round-robin over the 8 XCDs)
+    const int per_xcd = gridDim.x >> 3, bx = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    const int row0 = bx * kDuoRows;
+    if (row0 >= a.rows) return;   // whole workgroup, before any barrier
+    const int C2 = a.in_stride, nkc = a.in_stride / 128, nks = nkc * KS;
+    for (int i = t_; i < 2 * 128; i += NT) ((uint32_t*)(slab + kDuoSlabData + (i >> 7) * kDuoSlabBytes))[i & 127] = 0;
+    for (int i = t_; i < 9 * kDuoRows; i += NT) {
+        const int tap = i / kDuoRows, r = i - tap * kDuoRows, row = row0 + r;
+        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+        const int p = row % np, y = p / n, x = p - y * n;
+        const int src = (r + halo + dy * n + dx) * kSlabStride;
+        const bool ok = row < a.rows && (unsigned)(y + dy) < (unsigned)n && (unsigned)(x + dx) < (unsigned)n;
+        taptab[i] = (uint16_t)((ok ? src : kDuoSlabData + (src & 255)) >> 4);
+    }
+    // this thread's slab pieces: piece j = t_ + i*NT -> slab row j >> 3, 16-byte part j & 7
+    auto piece = [&](int i, int& src, int& dst) {
+        const int j = opaque(t_) + i * NT, srow = j >> 3, part = j & 7, grow = row0 - halo + srow;
+        dst = srow < srows ? srow * kSlabStride + part * 16 : -1;
+        src = (srow < srows && grow >= 0 && grow < a.rows) ? grow * C2 + part * 16 : -1;   // -1: outside the array, zeros
+    };
+#pragma unroll
+    for (int i = 0; i < kDuoPieces; ++i) {   // slab 0
+        int src, dst;
+        piece(i, src, dst);
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (src >= 0) v = *(const uint4*)(a.in + src);
+        if (dst >= 0) *(uint4*)(slab + dst) = v;
+    }
+    uint4 sp = make_uint4(0, 0, 0, 0);   // the piece of the next slab in flight
+    // k-step s, tile ni of this wave: byte (s * (C/16) + wn * NI + ni) * 1024 + lane * 16 of the packed image
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, nks * (C / 16) * 1024, 0x00020000);
+    const int wvoff = ((wn * NI) * 64 + lane) * 16;
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    auto wfrag = [&](int s, int ni) {
+        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff + ni * 1024, min(s, nks - 1) * (C / 16) * 1024, 0);
+        return __builtin_bit_cast(bf16x8, v);
+    };
+    const int kq16 = kq * 16;
+    const uint16_t* tb = taptab + lr;
+    f32x4 acc[MI][NI];
+    zero_acc<MI, NI>(acc);
+    bf16x8 af[AR], b[NB][NI];
+#pragma unroll
+    for (int d = 0; d < NB - 1; ++d)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) b[d][ni] = wfrag(d, ni);
+    int s = 0;
+#pragma nounroll
+    for (int kc = 0; kc < nkc; ++kc) {
+        const char* act = slab + (kc & 1) * kDuoSlabBytes;
+        char* nxt = slab + ((kc + 1) & 1) * kDuoSlabBytes;
+        const bool more = kc + 1 < nkc;
+        lds_barrier();   // slab kc (and, the first time, the table and the zero regions) is complete; nobody reads the other slab any more
+        int apc[MI];     // before a tap's first fragment of row tile mi is requested, the table entry; from then on the byte offset
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) apc[mi] = tb[mi * 16];
+#pragma unroll
+        for (int f = 0; f < AR; ++f) {
+            apc[f] = (apc[f] << 4) + kq16;
+            af[f] = *(const bf16x8*)(act + apc[f]);
+        }
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            if (more) {   // next slab: piece `tap` is fetched during tap `tap` and stored at the start of tap + 1
+                int src, dst;
+                if (tap >= 1 && tap <= kDuoPieces) {
+                    piece(tap - 1, src, dst);
+                    if (dst >= 0) *(uint4*)(nxt + dst) = sp;
+                }
+                if (tap < kDuoPieces) {
+                    piece(tap, src, dst);
+                    sp = make_uint4(0, 0, 0, 0);
+                    if (src >= 0) sp = *(const uint4*)(a.in + src + (kc + 1) * 128);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                const int u = f / MI, mi = f - u * MI, ks = tap * KPT + u;
+                if (mi == 0) {
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) b[(ks + NB - 1) % NB][ni] = wfrag(s + ks + NB - 1, ni);
+                }
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[ks % NB][ni], af[f % AR], acc[mi][ni], 0, 0, 0);
+                const int f2 = f + AR;
+                int ds_reads = 0;
+                if (f2 < NF) {
+                    const int m2 = f2 % MI, u2 = f2 / MI;
+                    if (u2 == 0) apc[m2] = (apc[m2] << 4) + kq16;   // row tiles AR..: first fragment of this tap
+                    af[f % AR] = *(const bf16x8*)(act + apc[m2] + u2 * 64);
+                    ds_reads = 1;
+                    if (u2 == KPT - 1 && tap < 8) { apc[m2] = tb[(tap + 1) * kDuoRows + m2 * 16]; ds_reads = 2; }   // the tile's last fragment of this tap
+                } else if (tap < 8) {   // the next tap's first fragments (row tiles 0..AR-1)
+                    const int m2 = f2 - NF;
+                    apc[m2] = (apc[m2] << 4) + kq16;
+                    af[f % AR] = *(const bf16x8*)(act + apc[m2]);
+                    ds_reads = 1;
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, NI, 0);
+                if (ds_reads == 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                else if (ds_reads == 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                if (mi < NI) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                if (mi == MI - 1) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        s += KS;
+    }
+    // epilogue: bias, ReLU, bf16 rows to global memory
+    const int cbase = col0 + 8 * kq;
+#pragma unroll
+    for (int p = 0; p < NI / 2; ++p) {
+        const float4 x0 = *(const float4*)(a.bias + cbase + 32 * p), x1 = *(const float4*)(a.bias + cbase + 32 * p + 4);
+        const float bv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int row = row0 + mi * 16 + lr;
+            float v[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { v[r] = acc[mi][2 * p][r] + bv[r]; v[4 + r] = acc[mi][2 * p + 1][r] + bv[4 + r]; }
+            if (a.relu) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
+            if (row < a.rows)
+                *(uint4*)(a.out + (size_t)row * a.out_stride + (size_t)(cbase + 32 * p) * 2) =
+                    make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
+        }
+    }
+}
+
 // [rows][32] bf16 feature rows -> [rows][64] (upper half zero): the stem then runs through the same tile loop.
 __global__ __launch_bounds__(256) void k_pad_features(const uint4* __restrict__ in, uint4* __restrict__ out, int rows, int np,
                                                       const int* rows_dev, int board_off) {
@@ -440,7 +603,7 @@ int layers_create(const az_net_config& c, const NetLayout& L, const float* Pm, L
     m->cfg = c;
     const int C = c.channels, np = c.board_size * c.board_size, q = C / 4;
     m->np = np; m->q = q;
-    m->ncols = C == 256 ? 128 : C;
+    m->ncols = C;   // 256 channels: k_conv3_duo (one block of all channels); below: k_conv3_slab<C>
     // boards per chunk: activation arrays of at most ~96 MiB each (measured at 19x19 256 channels: 32 MiB -6 %, 96-128 MiB +2 % over 64)
     m->chunk_boards = std::max(16, (int)(((size_t)96 << 20) / ((size_t)np * C * 2)));
     std::vector<float> w, b;
@@ -521,6 +684,13 @@ static int launch_slab(const ConvArgs& a, int cout, hipStream_t st) {
     return AZ_OK;
 }
 
+template <int C>
+static int launch_duo(const ConvArgs& a, hipStream_t st) {
+    const int row_tiles = (a.rows + kDuoRows - 1) / kDuoRows;
+    hipLaunchKernelGGL((k_conv3_duo<C>), dim3((unsigned)((row_tiles + 7) / 8 * 8)), dim3(256), (size_t)kDuoLds, st, a);
+    return AZ_OK;
+}
+
 // Tower convolutions: 4x2 waves of 64 positions x NCOLS/2 channels. Heads: 8x1 waves of 32 positions x all channels.
 static int launch_conv(const PackedConv& pc, const char* in, int zero_off, char* out, int out_stride, int rows, int n, int relu, bool head,
                        hipStream_t st, const int* rows_dev, int board_off) {
@@ -530,6 +700,7 @@ static int launch_conv(const PackedConv& pc, const char* in, int zero_off, char*
     a.out = out; a.out_stride = out_stride; a.rows = rows; a.n = n; a.np = n * n; a.ntaps = pc.taps; a.relu = relu; a.col_blocks = 1;
     const int key = (pc.cin_pad / 32) * 1000 + pc.ncols;
     if (pc.slab && n + 1 <= kMaxHalo) {
+        if (pc.ncols == 256 && pc.cout == 256) return launch_duo<256>(a, st);
         switch (pc.ncols) {
             case 64: return launch_slab<64>(a, pc.cout, st);
             case 128: return launch_slab<128>(a, pc.cout, st);
