@@ -4,7 +4,7 @@
 // double-buffered in LDS like in the fused tower (az_mfma_gemm.cuh). The 3x3 convolutions (k_conv3_slab) stage
 // the bf16 [position][channel] activations through LDS slabs; the 1x1 head (k_conv_layer) reads them from L2. The
 // squeeze-excite gate (pooled in position order, so a board's result does not depend on its neighbours in the
-// batch) and the residual add are two small bandwidth-bound kernels between the convolutions.
+// batch) and the residual add are one bandwidth-bound kernel between the convolutions (one workgroup per board).
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -430,15 +430,18 @@ __global__ __launch_bounds__(256) void k_pad_features(const uint4* __restrict__ 
 // phases; a thread adds every phases-th position of its 8 channels (16-byte loads, eight independent sums), then the
 // phases are added in index order. The order depends on the position within the board only, so a board's gate does not
 // depend on where the board sits in the batch.
-__global__ __launch_bounds__(256) void k_se_gate_layer(const uint16_t* __restrict__ y, int np, int C, int hid, const float* __restrict__ w1,
-                                                       const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2,
-                                                       float* __restrict__ gate, const int* rows_dev, int board_off) {
-    extern __shared__ float sh[];   // partial [phases][C], pooled [C], hidden [hid]
+// The board's gate stays in LDS and the same workgroup then applies it: x <- relu(y * gate + x) (model.py:38-40) for
+// the board's np x C values, 8 channels per thread and trip; y was just read for the pooling and comes from the L2.
+__global__ __launch_bounds__(256) void k_se_residual_layer(const uint16_t* __restrict__ y, int np, int C, int hid, const float* __restrict__ w1,
+                                                           const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2,
+                                                           uint16_t* __restrict__ x, const int* rows_dev, int board_off) {
+    extern __shared__ float sh[];   // partial [phases][C], pooled [C], hidden [hid], gate [C]
     if (rows_dev && (int)blockIdx.x >= *rows_dev - board_off) return;   // whole workgroup, before any barrier
     const int groups = C / 8, phases = 256 / groups;   // C in {64,128,192,256}: 8..32 groups; 192 -> 24 groups, 10 phases
     float* partial = sh;
     float* pooled = partial + phases * C;
     float* hidden = pooled + C;
+    float* gate = hidden + ((hid + 3) & ~3);
     const int t = threadIdx.x, b = blockIdx.x;
     const int grp = t % groups, ph = t / groups;
     if (ph < phases) {
@@ -496,7 +499,36 @@ __global__ __launch_bounds__(256) void k_se_gate_layer(const uint16_t* __restric
             const float4 w = *(const float4*)(wr + j);
             a = fmaf(w.x, hidden[j], a); a = fmaf(w.y, hidden[j + 1], a); a = fmaf(w.z, hidden[j + 2], a); a = fmaf(w.w, hidden[j + 3], a);
         }
-        gate[(size_t)b * C + ch] = 1.f / (1.f + __expf(-a));
+        gate[ch] = 1.f / (1.f + __expf(-a));
+    }
+    __syncthreads();
+    const uint4* yb = (const uint4*)(y + (size_t)b * np * C);
+    uint4* xb = (uint4*)(x + (size_t)b * np * C);
+    const int total = np * groups;   // 16-byte vectors of the board; thread t keeps channel group t % groups on every trip
+    float gv[8];
+    {
+        const float4 g0 = *(const float4*)(gate + grp * 8), g1 = *(const float4*)(gate + grp * 8 + 4);
+        gv[0] = g0.x; gv[1] = g0.y; gv[2] = g0.z; gv[3] = g0.w; gv[4] = g1.x; gv[5] = g1.y; gv[6] = g1.z; gv[7] = g1.w;
+    }
+    const int step = phases * groups;   // threads that take part (a multiple of groups, so the channel group is fixed)
+    auto apply = [&](const uint4& yv, const uint4& xv) {
+        const uint32_t yu[4] = {yv.x, yv.y, yv.z, yv.w}, xu[4] = {xv.x, xv.y, xv.z, xv.w};
+        uint32_t o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            o[k] = pack_bf16(fmaxf(bf16_lo(yu[k]) * gv[2 * k] + bf16_lo(xu[k]), 0.f), fmaxf(bf16_hi(yu[k]) * gv[2 * k + 1] + bf16_hi(xu[k]), 0.f));
+        return make_uint4(o[0], o[1], o[2], o[3]);
+    };
+    if (ph < phases) {
+        int i = t;
+        for (; i + 3 * step < total; i += 4 * step) {
+            uint4 yv[4], xv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { yv[k] = yb[i + k * step]; xv[k] = xb[i + k * step]; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) xb[i + k * step] = apply(yv[k], xv[k]);
+        }
+        for (; i < total; i += step) xb[i] = apply(yb[i], xb[i]);
     }
 }
 
@@ -540,7 +572,6 @@ struct LayerNet {
     std::vector<PackedConv> convs;     // 2 per block
     std::vector<float*> se;            // per block: w1, b1, w2, b2 (float32), empty without squeeze-excite
     char *f64 = nullptr, *x = nullptr, *h = nullptr, *y = nullptr;   // chunk activations, each followed by a zero region
-    float* gate = nullptr;
     size_t zero_off_f = 0, zero_off_c = 0;
 };
 
@@ -650,12 +681,6 @@ int layers_create(const az_net_config& c, const NetLayout& L, const float* Pm, L
         m->allocs.push_back(p);
         *bufs[i] = (char*)p;
     }
-    {
-        void* p = nullptr;
-        if (hipMalloc(&p, (size_t)m->chunk_boards * C * 4) != hipSuccess) { layers_destroy(m); return fail(AZ_ERR_HIP, "hipMalloc (gates)"); }
-        m->allocs.push_back(p);
-        m->gate = (float*)p;
-    }
 #undef TRY
     *out = m;
     return AZ_OK;
@@ -748,13 +773,11 @@ int layers_tower(LayerNet* m, const uint16_t* feat, int boards, uint16_t* hq, hi
         if (rc != AZ_OK) return rc;
         rc = launch_conv(m->convs[2 * i + 1], m->h, (int)m->zero_off_c, m->y, C * 2, rows, n, 0, false, st, rows_dev, board_off);
         if (rc != AZ_OK) return rc;
-        const float* gate = nullptr;
-        if (c.use_se) {
-            hipLaunchKernelGGL(k_se_gate_layer, dim3(boards), dim3(256), ((size_t)(256 / (C / 8)) * C + C + c.se_hidden) * 4, st, (const uint16_t*)m->y, np, C, c.se_hidden,
-                               m->se[4 * i], m->se[4 * i + 1], m->se[4 * i + 2], m->se[4 * i + 3], m->gate, rows_dev, board_off);
-            gate = m->gate;
-        }
-        hipLaunchKernelGGL(k_scale_residual, egrid, dim3(256), 0, st, (const uint4*)m->y, gate, (uint4*)m->x, rows, np, C, rows_dev, board_off);
+        if (c.use_se)
+            hipLaunchKernelGGL(k_se_residual_layer, dim3(boards), dim3(256), ((size_t)(256 / (C / 8)) * C + 2 * C + ((c.se_hidden + 3) & ~3)) * 4, st, (const uint16_t*)m->y, np, C,
+                               c.se_hidden, m->se[4 * i], m->se[4 * i + 1], m->se[4 * i + 2], m->se[4 * i + 3], (uint16_t*)m->x, rows_dev, board_off);
+        else
+            hipLaunchKernelGGL(k_scale_residual, egrid, dim3(256), 0, st, (const uint4*)m->y, (const float*)nullptr, (uint4*)m->x, rows, np, C, rows_dev, board_off);
     }
     rc = launch_conv(m->head, m->x, (int)m->zero_off_c, (char*)hq, 2 * m->q * 2, rows, n, 1, true, st, rows_dev, board_off);
     if (rc != AZ_OK) return rc;
