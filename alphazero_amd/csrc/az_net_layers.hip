@@ -8,7 +8,6 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
-#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -32,11 +31,6 @@ struct ConvArgs {
     int col_blocks;        // k_conv3_slab: blocks of NCOLS output channels (1-D grid, see slab_block)
     const int* rows_dev;   // if set: the batch's board count lives here; this launch covers boards board_off .. of it,
     int board_off;         // at most rows / np of them (rows is then the upper bound the grid was sized for)
-    // k_conv3_duo<C, true>: `in` holds y of the previous block; the convolution's input is x' = relu(y * gate + res)
-    // (model.py:38-40), formed while the slabs are staged; the workgroup writes x' of its own rows to res_out
-    const char* res = nullptr;
-    const float* gate = nullptr;   // [board][C]
-    char* res_out = nullptr;
 };
 
 // Rows this launch really has: all `rows` of them, or what the device-side board count leaves for its chunk.
@@ -258,36 +252,42 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_conv3_slab(Conv
     }
 }
 
-// The 3x3 convolution for C output channels as 256-thread workgroups, two per compute unit: 128 rows x all C output
-// channels each (4 waves = 4 channel quarters, every wave owns all 128 rows: 8 x C/64 accumulator tiles), so that one
+// The 3x3 convolution for C output channels as 256-thread workgroups, two per compute unit: 96 rows x all C output
+// channels each (4 waves = 4 channel quarters, every wave owns all 96 rows: 6 x C/64 accumulator tiles), so that one
 // workgroup's barriers, slab refills and epilogue run under the other's MFMAs. The activations go through the same
 // 64-channel slabs as in k_conv3_slab (the workgroup's rows + a halo of n+1 rows either side, double-buffered, a zero
 // region behind each slab); the weight fragments come straight from the packed global image (fragment order, chunk-major:
-// one coalesced 1 KiB load per fragment, two k-steps ahead), so LDS serves activation fragments only: 8 KiB of LDS reads
-// per 32 MFMAs and wave, half of what the 64 x 64 wave tiles with LDS-staged weights of k_conv3_slab need. Where a row
+// one coalesced 1 KiB load per fragment, two k-steps ahead), so LDS serves activation fragments only: one 1 KiB LDS read
+// per 4 MFMAs and wave, half of what the 64 x 64 wave tiles with LDS-staged weights of k_conv3_slab need. Where a row
 // tile's fragments of a tap start comes from a table in LDS built once per workgroup (offset / 16 of the tap's source row
 // in the slab, or of the bank-preserving spot in the zero region when the tap falls off the board). K order and hence
-// every output bit equal k_conv3_slab's.
-constexpr int kDuoRows = 128, kDuoSlabRows = kDuoRows + 2 * kMaxHalo, kDuoSlabData = kDuoSlabRows * kSlabStride;
+// every output bit equal k_conv3_slab's. Measured at 19x19, 256 channels, 20 blocks: 96 rows with two k-steps of weights
+// in flight 7.90 ms per 512 boards and 4.14 ms per 255; 128 rows with one k-step in flight (all the registers allow) 7.9-8.1
+// and 4.64 ms: the smaller tiles fill the last round of workgroups better.
+#ifndef AZ_DUO_ROWS
+#define AZ_DUO_ROWS 96
+#endif
+#ifndef AZ_DUO_NB
+#define AZ_DUO_NB 3   // weight fragment sets in the ring: the k-step in use + (AZ_DUO_NB - 1) in flight
+#endif
+constexpr int kDuoRows = AZ_DUO_ROWS, kDuoSlabRows = kDuoRows + 2 * kMaxHalo, kDuoSlabData = kDuoSlabRows * kSlabStride;
 constexpr int kDuoSlabBytes = kDuoSlabData + 512;                 // + zero region (kDuoSlabData is a multiple of 256)
 constexpr int kDuoPieces = (kDuoSlabRows * 8 + 255) / 256;       // 16-byte slab pieces per thread
-#ifndef AZ_DUO_NB
-#define AZ_DUO_NB 2   // weight fragment sets in the ring: the k-step in use + (AZ_DUO_NB - 1) in flight
-#endif
-constexpr int kDuoLds = 2 * kDuoSlabBytes + 9 * kDuoRows * 2;   // + 3 boards' gates for k_conv3_duo<C, true>
-static_assert(kDuoSlabData % 256 == 0 && kDuoPieces <= 8, "zero region alignment; one slab piece per tap is staged");
+constexpr int kDuoTab = 2 * kDuoSlabBytes;                      // the tap table, then a 16-byte trash slot per thread for
+constexpr int kDuoTrash = kDuoTab + 9 * kDuoRows * 2;           // slab pieces past the slab
+constexpr int kDuoLds = kDuoTrash + 256 * 16;
+static_assert(kDuoSlabData % 256 == 0 && kDuoTrash % 16 == 0 && kDuoPieces <= 7, "alignment; a slab piece is fetched at tap i and stored at tap i + 2");
 
 // Waits for this wave's LDS traffic only (the weight fragments in flight stay in flight), then the workgroup barrier.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int C, bool FUSE>
+template <int C>
 __global__ __launch_bounds__(256, 2) void k_conv3_duo(ConvArgs a) {
     constexpr int MI = kDuoRows / 16, NI = C / 64, WN = 4, NT = 256, KPT = 2, AR = 4, NF = KPT * MI, NB = AZ_DUO_NB, KS = 9 * KPT;
     static_assert(NI % 2 == 0 && NF % AR == 0 && KS % NB == 0, "tile pairs; static ring indices across taps and chunks");
     extern __shared__ __attribute__((aligned(256))) char smem[];
     char* slab = smem;
-    uint16_t* taptab = (uint16_t*)(smem + 2 * kDuoSlabBytes);
-    float* gt = (float*)(smem + kDuoLds);   // FUSE: the gates of the (at most 3) boards the slab rows belong to
+    uint16_t* taptab = (uint16_t*)(smem + kDuoTab);
     AZ_LANE_GEO(MI, NI, WN);
     a.rows = live_rows(a.rows, a.np, a.rows_dev, a.board_off);
     const int n = a.n, np = a.np, halo = n + 1, srows = kDuoRows + 2 * halo;
@@ -305,61 +305,36 @@ __global__ __launch_bounds__(256, 2) void k_conv3_duo(ConvArgs a) {
         const bool ok = row < a.rows && (unsigned)(y + dy) < (unsigned)n && (unsigned)(x + dx) < (unsigned)n;
         taptab[i] = (uint16_t)((ok ? src : kDuoSlabData + (src & 255)) >> 4);
     }
-    const int bfirst = max(row0 - halo, 0) / np, bnd1 = (bfirst + 1) * np, bnd2 = bnd1 + np;
-    if constexpr (FUSE) {
-        const int live = a.rows / np;
-        for (int i = t_; i < 3 * C; i += NT) {
-            const int b = bfirst + i / C;
-            gt[i] = b < live ? a.gate[(size_t)b * C + (i % C)] : 0.f;
-        }
-    }
-    // this thread's slab pieces: piece j = t_ + i*NT -> slab row j >> 3, 16-byte part j & 7; goff: where the piece's 8 gates
-    // of chunk 0 start in gt, or -1 - that for a row of the workgroup's own 128 (the rows whose x' it writes out)
-    auto piece = [&](int i, int& src, int& dst, int& goff) {
+    // this thread's slab pieces: piece j = t_ + i*NT -> slab row j >> 3, 16-byte part j & 7. src: the piece's byte offset
+    // in the input array for chunk 0, or kOob for rows outside the array (a buffer load from there gives zeros); dst:
+    // where it goes in a slab (a piece past the slab: the thread's trash slot). No branches: the staging code sits
+    // between the MFMAs of a tap's first k-step.
+    constexpr int kOob = (int)0x80000000;
+    auto piece = [&](int i, int& src, int& dst) {
         const int j = opaque(t_) + i * NT, srow = j >> 3, part = j & 7, grow = row0 - halo + srow;
-        dst = srow < srows ? srow * kSlabStride + part * 16 : -1;
-        src = (srow < srows && grow >= 0 && grow < a.rows) ? grow * C2 + part * 16 : -1;   // -1: outside the array, zeros
-        if constexpr (FUSE) {
-            goff = ((grow >= bnd1) + (grow >= bnd2)) * C + part * 8;
-            if (srow >= halo && srow < halo + kDuoRows) goff = -1 - goff;
-        }
+        dst = srow < srows ? srow * kSlabStride + part * 16 : kDuoTrash + (j & (NT - 1)) * 16;
+        src = (srow < srows && grow >= 0 && grow < a.rows) ? grow * C2 + part * 16 : kOob;
     };
-    // x' = relu(y * gate + x), the arithmetic of k_scale_residual
-    auto combine = [&](const uint4& yv, const uint4& xv, const float* g) {
-        const float4 g0 = *(const float4*)g, g1 = *(const float4*)(g + 4);
-        const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-        const uint32_t yu[4] = {yv.x, yv.y, yv.z, yv.w}, xu[4] = {xv.x, xv.y, xv.z, xv.w};
-        uint32_t o[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            o[k] = pack_bf16(fmaxf(bf16_lo(yu[k]) * gv[2 * k] + bf16_lo(xu[k]), 0.f), fmaxf(bf16_hi(yu[k]) * gv[2 * k + 1] + bf16_hi(xu[k]), 0.f));
-        return make_uint4(o[0], o[1], o[2], o[3]);
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (unsigned)a.rows * (unsigned)C2, 0x00020000);
+    // the fetch of piece i of chunk kcn (zeros when !live; src == kOob stays out of bounds: the array is far below 2 GiB)
+    auto get = [&](int i, int kcn, bool live) {
+        int src, dst;
+        piece(i, src, dst);
+        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(irs, live ? src + kcn * 128 : kOob, 0, 0);
+        return make_uint4(v.x, v.y, v.z, v.w);
     };
-    // a staged piece of chunk kcn -> the slab at sl (and, FUSE and an own row, x' -> res_out)
-    auto put = [&](char* sl, int src, int dst, int goff, int kcn, uint4 yv, const uint4& xv) {
-        if constexpr (FUSE) {
-            const bool own = goff < 0;
-            if (own) goff = -1 - goff;
-            yv = combine(yv, xv, gt + goff + kcn * 64);
-            if (own && src >= 0) *(uint4*)(a.res_out + src + kcn * 128) = yv;
-        }
-        if (dst >= 0) *(uint4*)(sl + dst) = yv;
-    };
-    if constexpr (FUSE) __syncthreads();   // gt is complete
 #pragma unroll
     for (int i = 0; i < kDuoPieces; ++i) {   // slab 0
-        int src, dst, goff = 0;
-        piece(i, src, dst, goff);
-        uint4 v = make_uint4(0, 0, 0, 0), xv = make_uint4(0, 0, 0, 0);
-        if (src >= 0) v = *(const uint4*)(a.in + src);
-        if constexpr (FUSE) { if (src >= 0) xv = *(const uint4*)(a.res + src); }
-        put(slab, src, dst, goff, 0, v, xv);
+        int src, dst;
+        piece(i, src, dst);
+        *(uint4*)(slab + dst) = get(i, 0, true);
     }
-    uint4 sp = make_uint4(0, 0, 0, 0), sq = make_uint4(0, 0, 0, 0);   // the piece of the next slab in flight (FUSE: y and x)
+    // the two pieces of the next slab in flight: fetched two taps before they are stored
+    uint4 sp[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
     // k-step s, tile ni of this wave: byte (s * (C/16) + wn * NI + ni) * 1024 + lane * 16 of the packed image
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, nks * (C / 16) * 1024, 0x00020000);
     const int wvoff = ((wn * NI) * 64 + lane) * 16;
-    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
     auto wfrag = [&](int s, int ni) {
         const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff + ni * 1024, min(s, nks - 1) * (C / 16) * 1024, 0);
         return __builtin_bit_cast(bf16x8, v);
@@ -390,23 +365,10 @@ __global__ __launch_bounds__(256, 2) void k_conv3_duo(ConvArgs a) {
         }
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            if (more) {   // next slab: piece `tap` is fetched during tap `tap` and stored at the start of tap + 1
-                int src, dst, goff = 0;
-                if (tap >= 1 && tap <= kDuoPieces) {
-                    piece(tap - 1, src, dst, goff);
-                    put(nxt, src, dst, goff, kc + 1, sp, sq);
-                }
-                if (tap < kDuoPieces) {
-                    piece(tap, src, dst, goff);
-                    sp = make_uint4(0, 0, 0, 0);
-                    if (src >= 0) sp = *(const uint4*)(a.in + src + (kc + 1) * 128);
-                    if constexpr (FUSE) {
-                        sq = make_uint4(0, 0, 0, 0);
-                        if (src >= 0) sq = *(const uint4*)(a.res + src + (kc + 1) * 128);
-                    }
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
+            // next slab: piece `tap` is fetched during tap `tap` (after MFMA group MI-2 of the first k-step) and stored
+            // during tap + 2 (after group 0); after the last chunk: zeros into the slab nobody reads any more. Fenced where
+            // they stand, so that the compiler neither bunches them up nor stretches their registers over the tap.
+            const bool putting = tap >= 2 && tap <= kDuoPieces + 1, getting = tap < kDuoPieces;
 #pragma unroll
             for (int f = 0; f < NF; ++f) {
                 const int u = f / MI, mi = f - u * MI, ks = tap * KPT + u;
@@ -434,6 +396,15 @@ __global__ __launch_bounds__(256, 2) void k_conv3_duo(ConvArgs a) {
                 if (ds_reads == 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
                 else if (ds_reads == 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 if (mi < NI) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                if (u == 0 && ((mi == 0 && putting) || (mi == MI - 2 && getting))) {
+                    if (mi == 0 && putting) {
+                        int src, dst;
+                        piece(tap - 2, src, dst);
+                        *(uint4*)(nxt + dst) = sp[tap & 1];
+                    }
+                    if (mi == MI - 2 && getting) sp[tap & 1] = get(tap, kc + 1, more);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 if (mi == MI - 1) __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -481,8 +452,7 @@ __global__ __launch_bounds__(256) void k_pad_features(const uint4* __restrict__ 
 // the board's np x C values, 8 channels per thread and trip; y was just read for the pooling and comes from the L2.
 __global__ __launch_bounds__(256) void k_se_residual_layer(const uint16_t* __restrict__ y, int np, int C, int hid, const float* __restrict__ w1,
                                                            const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2,
-                                                           uint16_t* __restrict__ x, float* __restrict__ gate_out, const int* rows_dev,
-                                                           int board_off) {
+                                                           uint16_t* __restrict__ x, const int* rows_dev, int board_off) {
     extern __shared__ float sh[];   // partial [phases][C], pooled [C], hidden [hid], gate [C]
     if (rows_dev && (int)blockIdx.x >= *rows_dev - board_off) return;   // whole workgroup, before any barrier
     const int groups = C / 8, phases = 256 / groups;   // C in {64,128,192,256}: 8..32 groups; 192 -> 24 groups, 10 phases
@@ -548,9 +518,7 @@ __global__ __launch_bounds__(256) void k_se_residual_layer(const uint16_t* __res
             a = fmaf(w.x, hidden[j], a); a = fmaf(w.y, hidden[j + 1], a); a = fmaf(w.z, hidden[j + 2], a); a = fmaf(w.w, hidden[j + 3], a);
         }
         gate[ch] = 1.f / (1.f + __expf(-a));
-        if (gate_out) gate_out[(size_t)b * C + ch] = gate[ch];
     }
-    if (gate_out) return;   // the next convolution applies the gate (k_conv3_duo<C, true>)
     __syncthreads();
     const uint4* yb = (const uint4*)(y + (size_t)b * np * C);
     uint4* xb = (uint4*)(x + (size_t)b * np * C);
@@ -622,8 +590,6 @@ struct LayerNet {
     std::vector<PackedConv> convs;     // 2 per block
     std::vector<float*> se;            // per block: w1, b1, w2, b2 (float32), empty without squeeze-excite
     char *f64 = nullptr, *x = nullptr, *h = nullptr, *y = nullptr;   // chunk activations, each followed by a zero region
-    char* x2 = nullptr;     // the second x array and the gates [board][C], when the convolutions apply the residual (layers_tower)
-    float* gate = nullptr;
     size_t zero_off_f = 0, zero_off_c = 0;
 };
 
@@ -663,10 +629,6 @@ static int pack_layer(LayerNet* m, const std::vector<float>& w, const std::vecto
     out->slab = slab;
     return AZ_OK;
 }
-
-// Whether the tower convolutions of this network run as k_conv3_duo, which can apply the previous block's gate and
-// residual while it stages its input.
-static bool duo_path(const az_net_config& c) { return c.channels == 256 && c.board_size + 1 <= kMaxHalo; }
 
 bool layers_supported(const az_net_config& c) {
     const bool cok = c.channels == 64 || c.channels == 128 || c.channels == 192 || c.channels == 256;
@@ -729,23 +691,13 @@ int layers_create(const az_net_config& c, const NetLayout& L, const float* Pm, L
     const size_t rows = (size_t)m->chunk_boards * np;
     m->zero_off_f = (rows * 128 + 255) / 256 * 256;
     m->zero_off_c = (rows * (size_t)C * 2 + 255) / 256 * 256;
-    // a slab's rows (128 + 2 halos) must not touch more than the 3 boards k_conv3_duo<C, true> keeps gates of: boards from 9x9
-    // (AZ_LAYER_FUSE=0 keeps the separate gate + residual kernel: same bits, for A/B runs and the equality test)
-    const char* fenv = getenv("AZ_LAYER_FUSE");
-    const bool fuse = c.use_se && duo_path(c) && c.board_size >= 9 && c.blocks > 1 && !(fenv && fenv[0] == '0');
-    char** bufs[5] = {&m->f64, &m->x, &m->h, &m->y, &m->x2};
-    for (int i = 0; i < (fuse ? 5 : 4); ++i) {
+    char** bufs[4] = {&m->f64, &m->x, &m->h, &m->y};
+    for (int i = 0; i < 4; ++i) {
         const size_t bytes = (i == 0 ? m->zero_off_f : m->zero_off_c) + kZeroTail;
         void* p = nullptr;
         if (hipMalloc(&p, bytes) != hipSuccess || hipMemset(p, 0, bytes) != hipSuccess) { layers_destroy(m); return fail(AZ_ERR_HIP, "hipMalloc (layer activations)"); }
         m->allocs.push_back(p);
         *bufs[i] = (char*)p;
-    }
-    if (fuse) {
-        void* p = nullptr;
-        if (hipMalloc(&p, (size_t)m->chunk_boards * C * 4) != hipSuccess) { layers_destroy(m); return fail(AZ_ERR_HIP, "hipMalloc (gates)"); }
-        m->allocs.push_back(p);
-        m->gate = (float*)p;
     }
 #undef TRY
     *out = m;
@@ -778,19 +730,14 @@ static int launch_slab(const ConvArgs& a, int cout, hipStream_t st) {
 template <int C>
 static int launch_duo(const ConvArgs& a, hipStream_t st) {
     const int row_tiles = (a.rows + kDuoRows - 1) / kDuoRows;
-    const dim3 grid((unsigned)((row_tiles + 7) / 8 * 8));
-    if (a.res) hipLaunchKernelGGL((k_conv3_duo<C, true>), grid, dim3(256), (size_t)kDuoLds + 3 * C * 4, st, a);
-    else hipLaunchKernelGGL((k_conv3_duo<C, false>), grid, dim3(256), (size_t)kDuoLds, st, a);
+    hipLaunchKernelGGL((k_conv3_duo<C>), dim3((unsigned)((row_tiles + 7) / 8 * 8)), dim3(256), (size_t)kDuoLds, st, a);
     return AZ_OK;
 }
 
-
 // Tower convolutions: 4x2 waves of 64 positions x NCOLS/2 channels. Heads: 8x1 waves of 32 positions x all channels.
 static int launch_conv(const PackedConv& pc, const char* in, int zero_off, char* out, int out_stride, int rows, int n, int relu, bool head,
-                       hipStream_t st, const int* rows_dev, int board_off, const char* res = nullptr, const float* gate = nullptr,
-                       char* res_out = nullptr) {
+                       hipStream_t st, const int* rows_dev, int board_off) {
     ConvArgs a;
-    a.res = res; a.gate = gate; a.res_out = res_out;
     a.rows_dev = rows_dev; a.board_off = board_off;
     a.in = in; a.in_stride = pc.cin_pad * 2; a.zero_off = zero_off; a.w = pc.w; a.w_block_vecs = pc.block_vecs; a.bias = pc.b;
     a.out = out; a.out_stride = out_stride; a.rows = rows; a.n = n; a.np = n * n; a.ntaps = pc.taps; a.relu = relu; a.col_blocks = 1;
@@ -839,33 +786,18 @@ int layers_tower(LayerNet* m, const uint16_t* feat, int boards, uint16_t* hq, hi
     if (rc != AZ_OK) return rc;
     const int per_row = C / 8;
     const dim3 egrid((unsigned)(((size_t)rows * per_row + 255) / 256));
-    // m->gate set: a block's gate kernel only writes the gates, and the next block's first convolution forms
-    // x' = relu(y * gate + x) while it stages its input, writing x' to the other of the two x arrays
-    char *xa = m->x, *xb = m->x2;
-    const size_t se_lds = ((size_t)(256 / (C / 8)) * C + 2 * C + ((c.se_hidden + 3) & ~3)) * 4;
     for (int i = 0; i < c.blocks; ++i) {
-        if (m->gate && i > 0) {
-            rc = launch_conv(m->convs[2 * i], m->y, (int)m->zero_off_c, m->h, C * 2, rows, n, 1, false, st, rows_dev, board_off, xa, m->gate, xb);
-            std::swap(xa, xb);
-        } else {
-            rc = launch_conv(m->convs[2 * i], xa, (int)m->zero_off_c, m->h, C * 2, rows, n, 1, false, st, rows_dev, board_off);
-        }
+        rc = launch_conv(m->convs[2 * i], m->x, (int)m->zero_off_c, m->h, C * 2, rows, n, 1, false, st, rows_dev, board_off);
         if (rc != AZ_OK) return rc;
         rc = launch_conv(m->convs[2 * i + 1], m->h, (int)m->zero_off_c, m->y, C * 2, rows, n, 0, false, st, rows_dev, board_off);
         if (rc != AZ_OK) return rc;
-        if (m->gate) {
-            hipLaunchKernelGGL(k_se_residual_layer, dim3(boards), dim3(256), se_lds, st, (const uint16_t*)m->y, np, C, c.se_hidden, m->se[4 * i], m->se[4 * i + 1],
-                               m->se[4 * i + 2], m->se[4 * i + 3], (uint16_t*)nullptr, m->gate, rows_dev, board_off);
-            if (i + 1 == c.blocks)
-                hipLaunchKernelGGL(k_scale_residual, egrid, dim3(256), 0, st, (const uint4*)m->y, (const float*)m->gate, (uint4*)xa, rows, np, C, rows_dev, board_off);
-        } else if (c.use_se) {
-            hipLaunchKernelGGL(k_se_residual_layer, dim3(boards), dim3(256), se_lds, st, (const uint16_t*)m->y, np, C, c.se_hidden, m->se[4 * i], m->se[4 * i + 1],
-                               m->se[4 * i + 2], m->se[4 * i + 3], (uint16_t*)xa, (float*)nullptr, rows_dev, board_off);
-        } else {
-            hipLaunchKernelGGL(k_scale_residual, egrid, dim3(256), 0, st, (const uint4*)m->y, (const float*)nullptr, (uint4*)xa, rows, np, C, rows_dev, board_off);
-        }
+        if (c.use_se)
+            hipLaunchKernelGGL(k_se_residual_layer, dim3(boards), dim3(256), ((size_t)(256 / (C / 8)) * C + 2 * C + ((c.se_hidden + 3) & ~3)) * 4, st, (const uint16_t*)m->y, np, C,
+                               c.se_hidden, m->se[4 * i], m->se[4 * i + 1], m->se[4 * i + 2], m->se[4 * i + 3], (uint16_t*)m->x, rows_dev, board_off);
+        else
+            hipLaunchKernelGGL(k_scale_residual, egrid, dim3(256), 0, st, (const uint4*)m->y, (const float*)nullptr, (uint4*)m->x, rows, np, C, rows_dev, board_off);
     }
-    rc = launch_conv(m->head, xa, (int)m->zero_off_c, (char*)hq, 2 * m->q * 2, rows, n, 1, true, st, rows_dev, board_off);
+    rc = launch_conv(m->head, m->x, (int)m->zero_off_c, (char*)hq, 2 * m->q * 2, rows, n, 1, true, st, rows_dev, board_off);
     if (rc != AZ_OK) return rc;
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return fail(AZ_ERR_HIP, std::string("bf16 layer path: ") + hipGetErrorString(err));

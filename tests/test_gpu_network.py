@@ -256,34 +256,6 @@ def test_bf16_layer_path(kw):
     assert torch.equal(lg[4:5], lg_1) and torch.equal(v[4:5], v_1)
 
 
-@pytest.mark.parametrize("kw,rows", [(dict(board_size=19, channels=256, num_blocks=3), 7),
-                                     (dict(board_size=9, channels=256, num_blocks=3, value_hidden_dim=64), 50),
-                                     (dict(board_size=13, channels=256, num_blocks=2), 11)],
-                         ids=lambda k: f"n{k['board_size']}" if isinstance(k, dict) else str(k))
-def test_layer_path_residual_applied_by_next_convolution_equals_separate_kernel(kw, rows, monkeypatch):
-    """256-channel towers on boards from 9x9: a block's gate kernel only writes the gates and the next block's first
-    convolution forms relu(y * gate + x) while it stages its input. Same bits as the separate gate + residual kernel
-    (AZ_LAYER_FUSE=0), on batches whose 128-row tiles straddle boards and end ragged."""
-    from alphazero_amd.model import AlphaZeroNet
-    import stubnets
-    torch.manual_seed(23)
-    dev = torch.device("cuda:0")
-    net = AlphaZeroNet(**kw).eval().to(dev)
-    n = kw["board_size"]
-    f = _to_nhwc_bf16(stubnets.synthetic_planes(rows, 21, n, seed=9)).to(dev)
-    nn_fused = net.native("bf16", shared=False)
-    lg_f, v_f = nn_fused(f)
-    monkeypatch.setenv("AZ_LAYER_FUSE", "0")
-    nn_sep = net.native("bf16", shared=False)
-    monkeypatch.delenv("AZ_LAYER_FUSE")
-    lg_s, v_s = nn_sep(f)
-    assert not nn_fused.fused and not nn_sep.fused
-    assert torch.equal(lg_f, lg_s) and torch.equal(v_f, v_s)
-    assert float(lg_f.abs().max()) > 0
-    lg_1, v_1 = nn_fused(f[rows // 2:rows // 2 + 1].contiguous())      # one board alone: same bits as inside the batch
-    assert torch.equal(lg_f[rows // 2:rows // 2 + 1], lg_1) and torch.equal(v_f[rows // 2:rows // 2 + 1], v_1)
-
-
 def test_layer_path_forward_indirect_equals_direct():
     """az_net_forward_indirect on the layer-by-layer path: the row count is read on the device, whole chunks are
     launched over the upper bound and surplus workgroups leave; the live rows equal az_net_forward's bit for bit and
