@@ -1,13 +1,14 @@
 """Mean per-launch counters of the tower kernel from a rocprofv3 --pmc counter_collection.csv, plus the figures derived
 from them: effective clock (GRBM_GUI_ACTIVE is summed over the 8 XCDs), share of all SIMD cycles the matrix pipes are busy
 (SQ_VALU_MFMA_BUSY_CYCLES counts cycles; 256 CUs x 4 SIMDs), split of the waves' cycles.
-  python tools/pmc_tower.py <counter_collection.csv> [min_grid]"""
+  python tools/pmc_tower.py <counter_collection.csv> [min_grid] [kernel name part, default k_tower]"""
 import collections
 import csv
 import json
 import sys
 
-rows = [r for r in csv.DictReader(open(sys.argv[1])) if "k_tower" in r["Kernel_Name"]]
+name = sys.argv[3] if len(sys.argv) > 3 else "k_tower"
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if name in r["Kernel_Name"]]
 min_grid = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 by = collections.defaultdict(list)
 dur = {}
