@@ -256,14 +256,15 @@ def test_bf16_layer_path(kw):
     assert torch.equal(lg[4:5], lg_1) and torch.equal(v[4:5], v_1)
 
 
-def test_layer_path_forward_indirect_equals_direct():
-    """az_net_forward_indirect on the layer-by-layer path: the row count is read on the device, whole chunks are
-    launched over the upper bound and surplus workgroups leave; the live rows equal az_net_forward's bit for bit and
-    rows past the count are left untouched."""
+@pytest.mark.parametrize("channels", [64, 256])
+def test_layer_path_forward_indirect_equals_direct(channels):
+    """az_net_forward_indirect on the layer-by-layer path (64 channels: k_conv3_slab; 256: k_conv3_duo): the row count is
+    read on the device, whole chunks are launched over the upper bound and surplus workgroups leave; the live rows equal
+    az_net_forward's bit for bit and rows past the count are left untouched."""
     from alphazero_amd.model import AlphaZeroNet
     import stubnets
     torch.manual_seed(12)
-    net = AlphaZeroNet(board_size=13, channels=64, num_blocks=2).eval()
+    net = AlphaZeroNet(board_size=13, channels=channels, num_blocks=2).eval()
     x = stubnets.synthetic_planes(40, 21, 13, seed=8)
     dev = torch.device("cuda:0")
     nn = net.to(dev).native("bf16", shared=False)
