@@ -30,6 +30,8 @@ bool layers_supported(const az_net_config& c);
 int layers_create(const az_net_config& c, const NetLayout& L, const float* params, LayerNet** out);
 void layers_destroy(LayerNet* m);
 int layers_chunk_boards(const LayerNet* m);
+int layers_cap_boards(const LayerNet* m);
+int layers_reserve(LayerNet* m, int boards);
 int layers_tower(LayerNet* m, const uint16_t* feat, int boards, uint16_t* hq, hipStream_t st, const int* rows_dev = nullptr, int board_off = 0);
 
 // bf16 MFMA path (az_net_mfma.hip)

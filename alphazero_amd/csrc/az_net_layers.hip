@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -39,21 +40,26 @@ __device__ __forceinline__ int live_rows(int rows, int np, const int* rows_dev, 
     return max(0, min(rows, (*rows_dev - board_off) * np));
 }
 
+// Every kernel of this file walks its tiles (or boards, or vectors) with a stride of the grid size: the grids are capped
+// (kPersistGrid), so a launch sized for an upper bound far above the device-side count costs no empty workgroups (a
+// workgroup that only reads the count and leaves still takes the dispatcher about 7 ns: 30 000 of them per launch made a
+// forward five times slower).
+constexpr int kPersistGrid = 2048;
+
+// One 256-row tile (row tile bx, block by of NCOLS output channels) of a convolution whose activation fragments come
+// straight from global memory (the 1x1 head; 3x3 shapes without a slab kernel). a.rows: the live rows.
 template <int KPT, int NCOLS, int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_conv_layer(ConvArgs a) {
+__device__ __forceinline__ void conv_layer_tile(const ConvArgs& a, int bx, int by, char* smem) {
     constexpr int MI = 256 / (WM * 16), NI = NCOLS / (WN * 16);
     static_assert(NI % 2 == 0, "channel tiles are stored in pairs");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    a.rows = live_rows(a.rows, a.np, a.rows_dev, a.board_off);
-    if ((int)blockIdx.x * 256 >= a.rows) return;   // whole workgroup, before any barrier
     TileGeo g;
-    g.row0 = blockIdx.x * 256; g.n = a.n; g.np = a.np; g.vrows = a.rows; g.recip_np = 0; g.recip_n = 0;
+    g.row0 = bx * 256; g.n = a.n; g.np = a.np; g.vrows = a.rows; g.recip_np = 0; g.recip_n = 0;
     f32x4 acc[MI][NI];
     zero_acc<MI, NI>(acc);
-    gemm_conv<MI, NI, WM, WN, NCOLS, KPT, true>(acc, a.w + (size_t)blockIdx.y * a.w_block_vecs, a.ntaps, a.ntaps == 9, a.in, a.in_stride,
+    gemm_conv<MI, NI, WM, WN, NCOLS, KPT, true>(acc, a.w + (size_t)by * a.w_block_vecs, a.ntaps, a.ntaps == 9, a.in, a.in_stride,
                                                   a.in + a.zero_off, smem, g);
     AZ_LANE_GEO(MI, NI, WN);
-    const int cbase = blockIdx.y * NCOLS + col0 + 8 * kq;
+    const int cbase = by * NCOLS + col0 + 8 * kq;
 #pragma unroll
     for (int p = 0; p < NI / 2; ++p) {
         const float4 x0 = *(const float4*)(a.bias + cbase + 32 * p), x1 = *(const float4*)(a.bias + cbase + 32 * p + 4);
@@ -75,6 +81,16 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_conv_layer(Conv
     }
 }
 
+template <int KPT, int NCOLS, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_conv_layer(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    a.rows = live_rows(a.rows, a.np, a.rows_dev, a.board_off);
+    for (int bx = blockIdx.x; bx * 256 < a.rows; bx += gridDim.x) {
+        if (bx != (int)blockIdx.x) __syncthreads();   // the previous tile's last weight fragments have been read
+        conv_layer_tile<KPT, NCOLS, WM, WN>(a, bx, blockIdx.y, smem);
+    }
+}
+
 // 3x3 convolution with the activations staged through LDS: the workgroup's 256 rows plus a halo of n+1 rows
 // on either side, 64 input channels at a time ("slab", row stride 160 B: conflict-free 16-byte fragment reads),
 // double-buffered; the nine taps of a channel chunk read the same slab at shifted rows, so every activation
@@ -84,25 +100,18 @@ constexpr int kSlabStride = 160, kMaxHalo = 20, kSlabRows = 256 + 2 * kMaxHalo, 
 constexpr int kSlabPieces = (kSlabRows * 8 + 511) / 512;   // 16-byte pieces per thread of a 512-thread workgroup
 
 template <int NCOLS, int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_conv3_slab(ConvArgs a) {
+__device__ __forceinline__ void conv3_slab_tile(const ConvArgs& a, int bx, int by, char* smem) {
     constexpr int NW = WM * WN, NT = 64 * NW;
     constexpr int MI = 256 / (WM * 16), NI = NCOLS / (WN * 16);
     constexpr int tile_bytes = 64 * NCOLS * 2, nvec = tile_bytes / 16, kstep_bytes = tile_bytes / 2;
     constexpr int NCHUNK = nvec / 64, PW = (NCHUNK + NW - 1) / NW;
     constexpr bool RAGGED = (NCHUNK % NW) != 0;
     static_assert(NI % 2 == 0 && NT == 512, "tile pairs; slab pieces are dealt to 512 threads");
-    extern __shared__ __attribute__((aligned(256))) char smem[];
     char* slab = smem;                         // two slabs
     char* zreg = smem + 2 * kSlabBytes;        // 1 KiB of zeros, 256-byte aligned (kSlabBytes is a multiple of 256)
     char* bbuf = zreg + 1024;                  // two weight tiles
     AZ_LANE_GEO(MI, NI, WN);
-    a.rows = live_rows(a.rows, a.np, a.rows_dev, a.board_off);
     const int n = a.n, np = a.np, halo = n + 1, srows = 256 + 2 * halo;
-    // 1-D grid; workgroups are dealt round-robin over the 8 XCDs, so ids 8 apart share an L2: the column blocks of one
-    // row tile get ids 8 apart and fetch the tile's activations into one L2 instead of one L2 each
-    const int per_group = 8 * a.col_blocks, grp = blockIdx.x / per_group, within = blockIdx.x - grp * per_group;
-    const int bx = grp * 8 + (within & 7), by = within >> 3;
-    if (bx * 256 >= a.rows) return;   // padding of the last group of 8 row tiles (whole workgroup, before any barrier)
     const int row0 = bx * 256, C2 = a.in_stride, nkc = a.in_stride / 128, ntiles = nkc * 9;
     const uint4* wg = a.w + (size_t)by * a.w_block_vecs;
     for (int i = t_; i < 256; i += NT) ((uint32_t*)zreg)[i] = 0;
@@ -252,6 +261,25 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_conv3_slab(Conv
     }
 }
 
+template <int NCOLS, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_conv3_slab(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(256))) char smem[];
+    a.rows = live_rows(a.rows, a.np, a.rows_dev, a.board_off);
+    // Workgroups are dealt round-robin over the 8 XCDs, so ids 8 apart share an L2: the column blocks of one row tile get
+    // (virtual) ids 8 apart and fetch the tile's activations into one L2 instead of one L2 each. The grid size is a
+    // multiple of 8 * col_blocks, so a workgroup's later tiles keep that property.
+    const int per_group = 8 * a.col_blocks, total = ((a.rows + 255) / 256 + 7) / 8 * per_group;
+    bool first = true;
+    for (int v = blockIdx.x; v < total; v += gridDim.x) {
+        const int grp = v / per_group, within = v - grp * per_group;
+        const int bx = grp * 8 + (within & 7), by = within >> 3;
+        if (bx * 256 >= a.rows) continue;   // padding of the last group of 8 row tiles (whole workgroup)
+        if (!first) __syncthreads();        // the previous tile's last LDS reads are done
+        first = false;
+        conv3_slab_tile<NCOLS, WM, WN>(a, bx, by, smem);
+    }
+}
+
 // The 3x3 convolution for C output channels as 256-thread workgroups, two per compute unit: 96 rows x all C output
 // channels each (4 waves = 4 channel quarters, every wave owns all 96 rows: 6 x C/64 accumulator tiles), so that one
 // workgroup's barriers, slab refills and epilogue run under the other's MFMAs. The activations go through the same
@@ -282,19 +310,14 @@ static_assert(kDuoSlabData % 256 == 0 && kDuoTrash % 16 == 0 && kDuoPieces <= 7,
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <int C>
-__global__ __launch_bounds__(256, 2) void k_conv3_duo(ConvArgs a) {
+__device__ __forceinline__ void conv3_duo_tile(const ConvArgs& a, int bx, char* smem) {
     constexpr int MI = kDuoRows / 16, NI = C / 64, WN = 4, NT = 256, KPT = 2, AR = 4, NF = KPT * MI, NB = AZ_DUO_NB, KS = 9 * KPT;
     static_assert(NI % 2 == 0 && NF % AR == 0 && KS % NB == 0, "tile pairs; static ring indices across taps and chunks");
-    extern __shared__ __attribute__((aligned(256))) char smem[];
     char* slab = smem;
     uint16_t* taptab = (uint16_t*)(smem + kDuoTab);
     AZ_LANE_GEO(MI, NI, WN);
-    a.rows = live_rows(a.rows, a.np, a.rows_dev, a.board_off);
     const int n = a.n, np = a.np, halo = n + 1, srows = kDuoRows + 2 * halo;
-    // consecutive row tiles share halo rows: give them to one XCD (workgroup ids are dealt round-robin over the 8 XCDs)
-    const int per_xcd = gridDim.x >> 3, bx = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     const int row0 = bx * kDuoRows;
-    if (row0 >= a.rows) return;   // whole workgroup, before any barrier
     const int C2 = a.in_stride, nkc = a.in_stride / 128, nks = nkc * KS;
     for (int i = t_; i < 2 * 128; i += NT) ((uint32_t*)(slab + kDuoSlabData + (i >> 7) * kDuoSlabBytes))[i & 127] = 0;
     for (int i = t_; i < 9 * kDuoRows; i += NT) {
@@ -433,14 +456,32 @@ __global__ __launch_bounds__(256, 2) void k_conv3_duo(ConvArgs a) {
     }
 }
 
+template <int C>
+__global__ __launch_bounds__(256, 2) void k_conv3_duo(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(256))) char smem[];
+    a.rows = live_rows(a.rows, a.np, a.rows_dev, a.board_off);
+    // consecutive row tiles share halo rows: give them to one XCD (workgroup ids are dealt round-robin over the 8 XCDs and
+    // the grid size is a multiple of 8, so a workgroup's tiles v, v + grid, ... all have v & 7 == its XCD)
+    const int per_xcd = ((a.rows + kDuoRows - 1) / kDuoRows + 7) >> 3;
+    bool first = true;
+    for (int v = blockIdx.x; v < 8 * per_xcd; v += gridDim.x) {
+        const int bx = (v & 7) * per_xcd + (v >> 3);
+        if (bx * kDuoRows >= a.rows) continue;   // whole workgroup
+        if (!first) __syncthreads();             // the previous tile's last LDS reads are done
+        first = false;
+        conv3_duo_tile<C>(a, bx, smem);
+    }
+}
+
 // [rows][32] bf16 feature rows -> [rows][64] (upper half zero): the stem then runs through the same tile loop.
 __global__ __launch_bounds__(256) void k_pad_features(const uint4* __restrict__ in, uint4* __restrict__ out, int rows, int np,
                                                       const int* rows_dev, int board_off) {
     rows = live_rows(rows, np, rows_dev, board_off);
-    const int i = blockIdx.x * 256 + threadIdx.x;   // one 16-byte piece of an output row (8 per row)
-    if (i >= rows * 8) return;
-    const int row = i >> 3, part = i & 7;
-    out[i] = part < 4 ? in[row * 4 + part] : make_uint4(0, 0, 0, 0);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)rows * 8; i += (size_t)gridDim.x * 256) {   // 16-byte pieces, 8 per output row
+        const size_t row = i >> 3;
+        const int part = (int)(i & 7);
+        out[i] = part < 4 ? in[row * 4 + part] : make_uint4(0, 0, 0, 0);
+    }
 }
 
 // Squeeze-excite gate of every board (model.py:9-22): mean over the board's positions, two small fully connected
@@ -452,16 +493,18 @@ __global__ __launch_bounds__(256) void k_pad_features(const uint4* __restrict__ 
 // the board's np x C values, 8 channels per thread and trip; y was just read for the pooling and comes from the L2.
 __global__ __launch_bounds__(256) void k_se_residual_layer(const uint16_t* __restrict__ y, int np, int C, int hid, const float* __restrict__ w1,
                                                            const float* __restrict__ b1, const float* __restrict__ w2, const float* __restrict__ b2,
-                                                           uint16_t* __restrict__ x, const int* rows_dev, int board_off) {
+                                                           uint16_t* __restrict__ x, int boards, const int* rows_dev, int board_off) {
     extern __shared__ float sh[];   // partial [phases][C], pooled [C], hidden [hid], gate [C]
-    if (rows_dev && (int)blockIdx.x >= *rows_dev - board_off) return;   // whole workgroup, before any barrier
+    if (rows_dev) boards = min(boards, *rows_dev - board_off);
     const int groups = C / 8, phases = 256 / groups;   // C in {64,128,192,256}: 8..32 groups; 192 -> 24 groups, 10 phases
     float* partial = sh;
     float* pooled = partial + phases * C;
     float* hidden = pooled + C;
     float* gate = hidden + ((hid + 3) & ~3);
-    const int t = threadIdx.x, b = blockIdx.x;
+    const int t = threadIdx.x;
     const int grp = t % groups, ph = t / groups;
+    for (int b = blockIdx.x; b < boards; b += gridDim.x) {
+    if (b != (int)blockIdx.x) __syncthreads();   // the previous board's gate has been read
     if (ph < phases) {
         const uint4* src = (const uint4*)(y + (size_t)b * np * C) + grp;
         float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -548,15 +591,15 @@ __global__ __launch_bounds__(256) void k_se_residual_layer(const uint16_t* __res
         }
         for (; i < total; i += step) xb[i] = apply(yb[i], xb[i]);
     }
+    }
 }
 
 // x <- relu(y * gate + x) (model.py:38-40), 8 channels per thread; gate == nullptr: no squeeze-excite.
 __global__ __launch_bounds__(256) void k_scale_residual(const uint4* __restrict__ y, const float* __restrict__ gate, uint4* __restrict__ x,
                                                         int rows, int np, int C, const int* rows_dev, int board_off) {
     rows = live_rows(rows, np, rows_dev, board_off);
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     const int per_row = C / 8;
-    if (i >= (size_t)rows * per_row) return;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)rows * per_row; i += (size_t)gridDim.x * 256) {
     const int row = (int)(i / per_row), c8 = (int)(i - (size_t)row * per_row) * 8;
     const uint4 yv = y[i], xv = x[i];
     const uint32_t yu[4] = {yv.x, yv.y, yv.z, yv.w}, xu[4] = {xv.x, xv.y, xv.z, xv.w};
@@ -571,6 +614,7 @@ __global__ __launch_bounds__(256) void k_scale_residual(const uint4* __restrict_
     for (int k = 0; k < 4; ++k)
         o[k] = pack_bf16(fmaxf(bf16_lo(yu[k]) * gv[2 * k] + bf16_lo(xu[k]), 0.f), fmaxf(bf16_hi(yu[k]) * gv[2 * k + 1] + bf16_hi(xu[k]), 0.f));
     x[i] = make_uint4(o[0], o[1], o[2], o[3]);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ host
@@ -585,6 +629,7 @@ struct PackedConv {
 struct LayerNet {
     az_net_config cfg;
     int np, q, chunk_boards, ncols;   // ncols: output channels per workgroup of the tower convolutions
+    int cap_boards = 0;               // boards the activation arrays hold (>= chunk_boards, see layers_reserve)
     std::vector<void*> allocs;
     PackedConv stem, head;
     std::vector<PackedConv> convs;     // 2 per block
@@ -644,6 +689,40 @@ void layers_destroy(LayerNet* m) {
 }
 
 int layers_chunk_boards(const LayerNet* m) { return m->chunk_boards; }
+int layers_cap_boards(const LayerNet* m) { return m->cap_boards; }
+
+// Activation arrays for passes of up to `boards` boards (at most what 31-bit byte offsets reach; never shrinks). A direct
+// forward still runs in chunks of chunk_boards; an indirect one covers its upper bound in passes of cap_boards, so a
+// caller that reserves its bound gets one pass. The arrays in use stay allocated until the network is destroyed (a launch
+// in flight may still read them).
+int layers_reserve(LayerNet* m, int boards) {
+    const int C = m->cfg.channels, np = m->np;
+    const int limit = (int)((((size_t)1 << 31) - kZeroTail) / ((size_t)np * C * 2)) - 1;
+    boards = std::min(std::max(boards, m->chunk_boards), std::max(limit, m->chunk_boards));
+    if (boards <= m->cap_boards) return AZ_OK;
+    if (hipSetDevice(m->cfg.device) != hipSuccess) return fail(AZ_ERR_HIP, "hipSetDevice");
+    const size_t rows = (size_t)boards * np;
+    const size_t zf = (rows * 128 + 255) / 256 * 256, zc = (rows * (size_t)C * 2 + 255) / 256 * 256;
+    char* fresh[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (int i = 0; i < 4; ++i) {
+        const size_t bytes = (i == 0 ? zf : zc) + kZeroTail;
+        void* p = nullptr;
+        if (hipMalloc(&p, bytes) != hipSuccess) {
+            for (int k = 0; k < i; ++k) (void)hipFree(fresh[k]);
+            return fail(AZ_ERR_HIP, "hipMalloc (layer activations)");
+        }
+        fresh[i] = (char*)p;
+        if (hipMemset(p, 0, bytes) != hipSuccess) {
+            for (int k = 0; k <= i; ++k) (void)hipFree(fresh[k]);
+            return fail(AZ_ERR_HIP, "hipMemset (layer activations)");
+        }
+    }
+    for (int i = 0; i < 4; ++i) m->allocs.push_back(fresh[i]);
+    m->f64 = fresh[0]; m->x = fresh[1]; m->h = fresh[2]; m->y = fresh[3];
+    m->zero_off_f = zf; m->zero_off_c = zc;
+    m->cap_boards = boards;
+    return AZ_OK;
+}
 
 int layers_create(const az_net_config& c, const NetLayout& L, const float* Pm, LayerNet** out) {
     if (!layers_supported(c)) return fail(AZ_ERR_ARG, "bf16 layer path: unsupported network shape");
@@ -655,6 +734,10 @@ int layers_create(const az_net_config& c, const NetLayout& L, const float* Pm, L
     m->ncols = C;   // 256 channels: k_conv3_duo (one block of all channels); below: k_conv3_slab<C>
     // boards per chunk: activation arrays of at most ~96 MiB each (measured at 19x19 256 channels: 32 MiB -6 %, 96-128 MiB +2 % over 64)
     m->chunk_boards = std::max(16, (int)(((size_t)96 << 20) / ((size_t)np * C * 2)));
+    if (const char* e = getenv("AZ_LAYER_CHUNK_BOARDS")) {   // diagnostics: another chunk size (byte offsets stay below 2 GiB)
+        const int v = atoi(e), cap = (int)(((size_t)1 << 31) / ((size_t)np * 256 * 2)) - 1;
+        if (v >= 16) m->chunk_boards = std::min(v, cap);
+    }
     std::vector<float> w, b;
     int rc;
 #define TRY(x) if ((rc = (x)) != AZ_OK) { layers_destroy(m); return rc; }
@@ -688,17 +771,7 @@ int layers_create(const az_net_config& c, const NetLayout& L, const float* Pm, L
         std::copy(bv.begin(), bv.end(), bh.begin() + q);
         TRY(pack_layer(m, wh, bh, 2 * q, C, 1, C, 2 * q, &m->head));
     }
-    const size_t rows = (size_t)m->chunk_boards * np;
-    m->zero_off_f = (rows * 128 + 255) / 256 * 256;
-    m->zero_off_c = (rows * (size_t)C * 2 + 255) / 256 * 256;
-    char** bufs[4] = {&m->f64, &m->x, &m->h, &m->y};
-    for (int i = 0; i < 4; ++i) {
-        const size_t bytes = (i == 0 ? m->zero_off_f : m->zero_off_c) + kZeroTail;
-        void* p = nullptr;
-        if (hipMalloc(&p, bytes) != hipSuccess || hipMemset(p, 0, bytes) != hipSuccess) { layers_destroy(m); return fail(AZ_ERR_HIP, "hipMalloc (layer activations)"); }
-        m->allocs.push_back(p);
-        *bufs[i] = (char*)p;
-    }
+    TRY(layers_reserve(m, m->chunk_boards));
 #undef TRY
     *out = m;
     return AZ_OK;
@@ -706,7 +779,7 @@ int layers_create(const az_net_config& c, const NetLayout& L, const float* Pm, L
 
 template <int KPT, int NCOLS, int WM, int WN>
 static void launch_one(const ConvArgs& a, int cout, hipStream_t st) {
-    const dim3 grid((a.rows + 255) / 256, (cout + NCOLS - 1) / NCOLS);
+    const dim3 grid(std::min((a.rows + 255) / 256, kPersistGrid), (cout + NCOLS - 1) / NCOLS);
     hipLaunchKernelGGL((k_conv_layer<KPT, NCOLS, WM, WN>), grid, dim3(64 * WM * WN), (size_t)2 * 64 * NCOLS * 2, st, a);
 }
 
@@ -722,7 +795,7 @@ static int launch_slab(const ConvArgs& a, int cout, hipStream_t st) {
     ConvArgs b = a;
     b.col_blocks = (cout + NCOLS - 1) / NCOLS;
     const int row_tiles = (a.rows + 255) / 256;
-    const dim3 grid((unsigned)((row_tiles + 7) / 8 * 8 * b.col_blocks));
+    const dim3 grid((unsigned)std::min((row_tiles + 7) / 8 * 8 * b.col_blocks, kPersistGrid));   // both multiples of 8 * col_blocks
     hipLaunchKernelGGL((k_conv3_slab<NCOLS, 4, 2>), grid, dim3(512), lds, st, b);
     return AZ_OK;
 }
@@ -730,7 +803,7 @@ static int launch_slab(const ConvArgs& a, int cout, hipStream_t st) {
 template <int C>
 static int launch_duo(const ConvArgs& a, hipStream_t st) {
     const int row_tiles = (a.rows + kDuoRows - 1) / kDuoRows;
-    hipLaunchKernelGGL((k_conv3_duo<C>), dim3((unsigned)((row_tiles + 7) / 8 * 8)), dim3(256), (size_t)kDuoLds, st, a);
+    hipLaunchKernelGGL((k_conv3_duo<C>), dim3((unsigned)std::min((row_tiles + 7) / 8 * 8, kPersistGrid)), dim3(256), (size_t)kDuoLds, st, a);
     return AZ_OK;
 }
 
@@ -780,20 +853,21 @@ int layers_tower(LayerNet* m, const uint16_t* feat, int boards, uint16_t* hq, hi
     const az_net_config& c = m->cfg;
     const int C = c.channels, n = c.board_size, np = m->np, rows = boards * np;
     if (boards <= 0) return AZ_OK;
-    if (boards > m->chunk_boards) return fail(AZ_ERR_ARG, "layers_tower: chunk too large");
-    hipLaunchKernelGGL(k_pad_features, dim3((rows * 8 + 255) / 256), dim3(256), 0, st, (const uint4*)feat, (uint4*)m->f64, rows, np, rows_dev, board_off);
+    if (boards > m->cap_boards) return fail(AZ_ERR_ARG, "layers_tower: more boards than the activation arrays hold");
+    hipLaunchKernelGGL(k_pad_features, dim3(std::min((rows * 8 + 255) / 256, kPersistGrid)), dim3(256), 0, st, (const uint4*)feat, (uint4*)m->f64, rows, np, rows_dev, board_off);
     int rc = launch_conv(m->stem, m->f64, (int)m->zero_off_f, m->x, C * 2, rows, n, 1, false, st, rows_dev, board_off);
     if (rc != AZ_OK) return rc;
     const int per_row = C / 8;
-    const dim3 egrid((unsigned)(((size_t)rows * per_row + 255) / 256));
+    const dim3 egrid((unsigned)std::min<size_t>(((size_t)rows * per_row + 255) / 256, 2 * kPersistGrid));
     for (int i = 0; i < c.blocks; ++i) {
         rc = launch_conv(m->convs[2 * i], m->x, (int)m->zero_off_c, m->h, C * 2, rows, n, 1, false, st, rows_dev, board_off);
         if (rc != AZ_OK) return rc;
         rc = launch_conv(m->convs[2 * i + 1], m->h, (int)m->zero_off_c, m->y, C * 2, rows, n, 0, false, st, rows_dev, board_off);
         if (rc != AZ_OK) return rc;
         if (c.use_se)
-            hipLaunchKernelGGL(k_se_residual_layer, dim3(boards), dim3(256), ((size_t)(256 / (C / 8)) * C + 2 * C + ((c.se_hidden + 3) & ~3)) * 4, st, (const uint16_t*)m->y, np, C,
-                               c.se_hidden, m->se[4 * i], m->se[4 * i + 1], m->se[4 * i + 2], m->se[4 * i + 3], (uint16_t*)m->x, rows_dev, board_off);
+            hipLaunchKernelGGL(k_se_residual_layer, dim3(std::min(boards, kPersistGrid)), dim3(256), ((size_t)(256 / (C / 8)) * C + 2 * C + ((c.se_hidden + 3) & ~3)) * 4, st,
+                               (const uint16_t*)m->y, np, C, c.se_hidden, m->se[4 * i], m->se[4 * i + 1], m->se[4 * i + 2], m->se[4 * i + 3], (uint16_t*)m->x, boards, rows_dev,
+                               board_off);
         else
             hipLaunchKernelGGL(k_scale_residual, egrid, dim3(256), 0, st, (const uint4*)m->y, (const float*)nullptr, (uint4*)m->x, rows, np, C, rows_dev, board_off);
     }

@@ -716,7 +716,12 @@ template <int NTW>
 __global__ __launch_bounds__(256) void k_value_tail_mfma(const uint16_t* __restrict__ hq, const uint4* __restrict__ w4p, const float* __restrict__ b4p,
                                                          const float* __restrict__ w6p, const float* __restrict__ b6, float* __restrict__ values,
                                                          int rows, int np, int q, int nks, int ntiles, unsigned recip_qc, const int* rows_dev, int row_off, float* part_out, int part_stride) {
-    value_tail_body<NTW>(blockIdx.x, blockIdx.y, hq, w4p, b4p, w6p, b6, values, rows, np, q, nks, ntiles, recip_qc, rows_dev, row_off, part_out, part_stride);
+    // units of 16 boards with a stride of the grid, which run_tails caps for a launch over an upper bound
+    const int live = rows_dev ? min(rows, *rows_dev - row_off) : rows;
+    for (int bx = blockIdx.x; bx * 16 < live; bx += gridDim.x) {
+        if (bx != (int)blockIdx.x) __syncthreads();   // `red` of the previous unit has been read
+        value_tail_body<NTW>(bx, blockIdx.y, hq, w4p, b4p, w6p, b6, values, rows, np, q, nks, ntiles, recip_qc, rows_dev, row_off, part_out, part_stride);
+    }
 }
 
 // Both tails in one launch (boards up to 9x9, un-split value tail). The two read the same head activations and are independent, so they share the machine instead of running
@@ -1013,7 +1018,11 @@ int mfma_reserve(MfmaNet* m, int rows) {
     if (rows < 1) return fail(AZ_ERR_ARG, "az_net_reserve: rows must be >= 1");
     if (hipSetDevice(m->cfg.device) != hipSuccess) return fail(AZ_ERR_HIP, "hipSetDevice");
     const int np = m->cfg.board_size * m->cfg.board_size;
-    if (m->layers) rows = std::min(rows, layers_chunk_boards(m->layers));   // larger batches run chunk by chunk
+    if (m->layers) {   // a pass holds at most what the activation arrays can (larger batches run pass by pass)
+        int rcl = layers_reserve(m->layers, rows);
+        if (rcl != AZ_OK) return rcl;
+        rows = std::min(rows, layers_cap_boards(m->layers));
+    }
     if (rows <= m->hq_rows) return AZ_OK;
     uint16_t* h = nullptr;
     if (hipMalloc((void**)&h, (size_t)rows * np * 2 * m->q * 2) != hipSuccess) return fail(AZ_ERR_HIP, "hipMalloc (head scratch)");
@@ -1141,7 +1150,10 @@ static void run_tails(MfmaNet* m, const uint16_t* hq_in, int rows, const int* ro
         hipLaunchKernelGGL((k_policy_tail<2>), dim3((rows + 1) / 2), dim3(256), (size_t)2 * 2 * np * 4, st, hq_in, m->w3, m->b3, m->wfcT, m->bfc, logits, rows,
                            np, q, rows_dev, row_off);
     if (m->w4p) {
-        const dim3 vg((rows + 15) / 16);
+        // over an upper bound: few workgroups, each walking the live units with the grid's stride. With one workgroup per unit
+        // of the bound (512 x 4 for 8192 boards, 32 x 4 of them live) the live ones, first in line, were packed onto a few
+        // compute units: 414 us instead of 127 us per launch
+        const dim3 vg(rows_dev ? std::min((rows + 15) / 16, 64) : (rows + 15) / 16);
         const uint4* wp = (const uint4*)m->w4p;
         const int shares = (m->v_ntiles + 3) / 4;
         if (m->vpart && shares > 1) {
@@ -1290,12 +1302,13 @@ static int fused_forward(MfmaNet* m, const void* feat, int rows, const int* rows
     return AZ_OK;
 }
 
-// Launch sequences an indirect forward over `max_rows` rows makes: 1 for the fused tower; for the layer path one per chunk
-// of the upper bound (each pass past the live rows costs its empty launches).
+// Launch sequences an indirect forward over `max_rows` rows makes: 1 for the fused tower; for the layer path one per
+// activation-array capacity of the upper bound (az_net_reserve(max_rows) grows the arrays, up to 2 GiB each, so that it is 1;
+// each pass past the live rows costs its launches of workgroups that leave at once).
 int mfma_indirect_passes(const MfmaNet* m, int max_rows) {
     if (!m->layers) return 1;
-    const int chunk = layers_chunk_boards(m->layers);
-    return (max_rows + chunk - 1) / chunk;
+    const int cap = layers_cap_boards(m->layers);
+    return (max_rows + cap - 1) / cap;
 }
 
 // Whether an indirect forward over `max_rows` rows consists of kernel launches only, with nothing that a stream capture
@@ -1309,13 +1322,13 @@ int mfma_forward(MfmaNet* m, const void* feat, int rows, const int* rows_dev, fl
     const az_net_config& c = m->cfg;
     const int np = c.board_size * c.board_size;
     if (m->layers) {
-        const int chunk = layers_chunk_boards(m->layers), A = np + 1;   // hq / vpart hold one chunk (mfma_create)
+        const int chunk = layers_chunk_boards(m->layers), A = np + 1;   // hq / vpart hold one pass (mfma_reserve)
         std::pair<hipEvent_t, hipEvent_t>* evl = nullptr;
         int rcp = prof_begin(m, rows_dev ? 0 : rows, st, &evl);
         if (rcp != AZ_OK) return rcp;
         // direct: even shares, no small last chunk. indirect: whole chunks over the upper bound; the workgroups of a chunk
         // past the device-side count leave at once, so a batch that fills one chunk pays for the others' empty launches only
-        const int nchunks = (rows + chunk - 1) / chunk, per = rows_dev ? chunk : (rows + nchunks - 1) / nchunks;
+        const int nchunks = (rows + chunk - 1) / chunk, per = rows_dev ? layers_cap_boards(m->layers) : (rows + nchunks - 1) / nchunks;
         for (int off = 0; off < rows; off += per) {
             const int nb = std::min(per, rows - off);
             int rc = layers_tower(m->layers, (const uint16_t*)feat + (size_t)off * np * 32, nb, m->hq, st, rows_dev, off);

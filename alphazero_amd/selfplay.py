@@ -181,12 +181,13 @@ class _Lane:
             self.root_reuse = self.net is not None and precision == "bf16" and owner.reuse_roots
             if self.root_reuse:
                 self.eng.set_root_reuse(True)
-            # with the native bf16 network the batches of a search are enqueued without host round trips, unless the
-            # layer-by-layer path would pay for empty chunk passes over the upper bound (then: one round trip per batch)
-            self.can_async = self.net is not None and precision == "bf16" and self.net.indirect
-            self.async_search = self.can_async and self.net.indirect_passes(self.max_rows) == 1
             if self.net is not None and precision == "bf16":
                 self.net.reserve(self.max_rows)      # no allocation inside the move loop
+            # with the native bf16 network the batches of a search are enqueued without host round trips, unless the
+            # layer-by-layer path cannot hold the upper bound in its activation arrays (2 GiB each at most) and would pay
+            # for empty passes over it (then: one round trip per batch)
+            self.can_async = self.net is not None and precision == "bf16" and self.net.indirect
+            self.async_search = self.can_async and self.net.indirect_passes(self.max_rows) == 1
             if self.async_search:
                 self.eng.set_async(True)
                 self.rows_dev = self.eng.rows_device()

@@ -298,6 +298,7 @@ def main():
     ap.add_argument("--no-dedup", action="store_true", help="evaluate repeated leaves of a batch again, as upstream does")
     ap.add_argument("--lanes", type=int, default=0, help="independent game lanes (engine + stream each) whose kernels and host work overlap (0: the configuration's)")
     ap.add_argument("--tower-workgroups", type=int, default=0, help="workgroup limit per tower launch (0: one per CU with 1 lane, 1024 otherwise)")
+    ap.add_argument("--sync-search", action="store_true", help="one host round trip per inference batch instead of enqueueing a move's batches back to back (A/B timing)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="search time per CPU-baseline leg")
     ap.add_argument("--no-side-legs", action="store_true", help="skip the no-dedup window, the kernel census and the plies-per-game run")
@@ -374,6 +375,8 @@ def main():
 
     sp = BatchedSelfPlay(net, cfg, games=a.games, seed0=1 + rank * a.games, dedup_leaves=not a.no_dedup, lanes=a.lanes,
                          tower_workgroups=twg)
+    if a.sync_search:
+        sp.set_async(False)
     with PowerWatch(local) as pw:
         dt, (tower_ms_sum, launches, tower_ms) = window(sp, a.steps, a.warmup, watch=pw)   # tower_ms: merged (overlap counted once)
 

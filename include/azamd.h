@@ -177,7 +177,9 @@ int az_net_forward(az_net* net, const void* feat_dev, int32_t rows, float* logit
 /* Allocate the activation scratch for forwards of up to `rows` positions now, so that az_net_forward /
  * az_net_forward_indirect calls of that size allocate nothing and never wait for the device (without it the scratch
  * grows at the first larger call; a replaced buffer is kept until az_net_destroy because enqueued launches may
- * still use it). Same role as the lazily built torch workspace behind model(x) in mcts.py:59-64. */
+ * still use it). A layer-by-layer network (boards above 9x9, 256 channels) also grows its activation arrays to `rows`
+ * boards, up to 2 GiB per array, so that az_net_forward_indirect covers an upper bound of `rows` in one pass. Same role
+ * as the lazily built torch workspace behind model(x) in mcts.py:59-64. */
 int az_net_reserve(az_net* net, int32_t rows);
 
 /* *fused = 1 if the bf16 network runs as the single fused tower kernel (boards up to 9x9, up to 192 channels), 0 if
@@ -199,8 +201,9 @@ int az_net_forward_static(az_net* net, const void* feat_dev, int32_t rows, float
 int64_t az_net_static_max_rows(const az_net* net);
 
 /* How many launch sequences az_net_forward_indirect makes for an upper bound of max_rows: 1 for a fused network; a
- * layer-by-layer network runs one sequence per chunk of the bound, and the sequences past the live rows are empty
- * launches that still cost their dispatch, so a caller may prefer one host round trip per batch when this exceeds 1. */
+ * layer-by-layer network runs one sequence per capacity of its activation arrays (az_net_reserve(max_rows) makes that 1
+ * unless an array would pass 2 GiB), and the sequences past the live rows are empty launches that still cost their
+ * dispatch, so a caller may prefer one host round trip per batch when this exceeds 1. */
 int az_net_indirect_passes(const az_net* net, int32_t max_rows);
 
 /* 1 if az_net_forward_indirect over max_rows rows is launches only (one pass, scratch reserved by az_net_reserve, launch

@@ -284,6 +284,34 @@ def test_lockstep_selfplay_on_19x19_layer_path():
     assert logs[0][1]["nn_rows"] == logs[1][1]["nn_rows"]
 
 
+def test_layer_path_selfplay_row_bound_above_one_chunk_stays_asynchronous():
+    """A layer-path search whose row bound (games x inference batch) is above the network's default chunk: reserving the
+    bound grows the activation arrays, so the batches are still enqueued without round trips in one pass (the kernels
+    walk their tiles with a capped grid: workgroups past the live rows would otherwise cost more than the live ones);
+    one round trip per batch plays the same moves."""
+    import torch
+    from alphazero_amd.model import AlphaZeroNet
+    from alphazero_amd.selfplay import BatchedSelfPlay, SelfPlayConfig
+    torch.manual_seed(6)
+    net = AlphaZeroNet(board_size=19, channels=64, num_blocks=1).eval().cuda()
+    cfg = SelfPlayConfig(board_size=19, mcts_simulations=32, mcts_inference_batch=16, mcts_topk_expand=16)
+    games = 160
+    logs = []
+    for use_async in (True, False):
+        sp = BatchedSelfPlay(net, cfg, games=games, seed0=3, lanes=1)
+        ln = sp.lanes[0]
+        assert ln.max_rows == games * 16 and ln.max_rows > 2178        # 96 MiB / (361 positions x 64 channels x 2 bytes)
+        assert not sp.net.fused and ln.net.indirect_passes(ln.max_rows) == 1 and sp.async_search
+        sp.set_async(use_async)
+        sp.begin(num_games=games)
+        for _ in range(2):
+            sp.step()
+        assert sp.counters["sims"] == 2 * games * 32
+        logs.append([x[2].copy() for x in sp.log])
+    for pa, pb in zip(*logs):
+        assert np.array_equal(pa, pb)
+
+
 def test_bench_line_contract():
     """bench.py prints one JSON line with the fields the driver reads (small game count so it takes seconds)."""
     import json as _json
