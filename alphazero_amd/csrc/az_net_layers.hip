@@ -292,27 +292,33 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void k_conv3_slab(Conv
 // every output bit equal k_conv3_slab's. Measured at 19x19, 256 channels, 20 blocks: 96 rows with two k-steps of weights
 // in flight 7.90 ms per 512 boards and 4.14 ms per 255; 128 rows with one k-step in flight (all the registers allow) 7.9-8.1
 // and 4.64 ms: the smaller tiles fill the last round of workgroups better.
-#ifndef AZ_DUO_ROWS
-#define AZ_DUO_ROWS 96
-#endif
 #ifndef AZ_DUO_NB
 #define AZ_DUO_NB 3   // weight fragment sets in the ring: the k-step in use + (AZ_DUO_NB - 1) in flight
 #endif
-constexpr int kDuoRows = AZ_DUO_ROWS, kDuoSlabRows = kDuoRows + 2 * kMaxHalo, kDuoSlabData = kDuoSlabRows * kSlabStride;
-constexpr int kDuoSlabBytes = kDuoSlabData + 512;                 // + zero region (kDuoSlabData is a multiple of 256)
-constexpr int kDuoPieces = (kDuoSlabRows * 8 + 255) / 256;       // 16-byte slab pieces per thread
-constexpr int kDuoTab = 2 * kDuoSlabBytes;                      // the tap table, then a 16-byte trash slot per thread for
-constexpr int kDuoTrash = kDuoTab + 9 * kDuoRows * 2;           // slab pieces past the slab
-constexpr int kDuoLds = kDuoTrash + 256 * 16;
-static_assert(kDuoSlabData % 256 == 0 && kDuoTrash % 16 == 0 && kDuoPieces <= 7, "alignment; a slab piece is fetched at tap i and stored at tap i + 2");
+template <int ROWS>
+struct DuoGeo {   // LDS layout of a workgroup of ROWS rows
+    static constexpr int kRows = ROWS, kSlabRows = ROWS + 2 * kMaxHalo, kSlabData = kSlabRows * kSlabStride;
+    static constexpr int kSlabBytes = kSlabData + 512;             // + zero region (kSlabData is a multiple of 256)
+    static constexpr int kPieces = (kSlabRows * 8 + 255) / 256;   // 16-byte slab pieces per thread
+    static constexpr int kTab = 2 * kSlabBytes;                   // the tap table, then a 16-byte trash slot per thread for
+    static constexpr int kTrash = kTab + 9 * ROWS * 2;            // slab pieces past the slab
+    static constexpr int kLds = kTrash + 256 * 16;
+    static_assert(kSlabData % 256 == 0 && kTrash % 16 == 0 && kPieces <= 7, "alignment; a slab piece is fetched at tap i and stored at tap i + 2");
+};
+// Rows per workgroup by channel count: 256 channels (4 accumulator tiles per row tile and wave) 96, which leaves the
+// registers for two k-steps of weights in flight; 192 channels (3 tiles, the third unpaired: pack_conv slab_tiles) 128.
+template <int C> struct DuoRows { static constexpr int value = C == 256 ? 96 : 128; };
 
 // Waits for this wave's LDS traffic only (the weight fragments in flight stay in flight), then the workgroup barrier.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <int C>
 __device__ __forceinline__ void conv3_duo_tile(const ConvArgs& a, int bx, char* smem) {
+    typedef DuoGeo<DuoRows<C>::value> G;
+    constexpr int kDuoRows = G::kRows, kDuoSlabData = G::kSlabData, kDuoSlabBytes = G::kSlabBytes, kDuoPieces = G::kPieces, kDuoTab = G::kTab,
+                  kDuoTrash = G::kTrash;
     constexpr int MI = kDuoRows / 16, NI = C / 64, WN = 4, NT = 256, KPT = 2, AR = 4, NF = KPT * MI, NB = AZ_DUO_NB, KS = 9 * KPT;
-    static_assert(NI % 2 == 0 && NF % AR == 0 && KS % NB == 0, "tile pairs; static ring indices across taps and chunks");
+    static_assert(C % 64 == 0 && NF % AR == 0 && KS % NB == 0, "whole tiles per wave; static ring indices across taps and chunks");
     char* slab = smem;
     uint16_t* taptab = (uint16_t*)(smem + kDuoTab);
     AZ_LANE_GEO(MI, NI, WN);
@@ -454,10 +460,24 @@ __device__ __forceinline__ void conv3_duo_tile(const ConvArgs& a, int bx, char* 
                     make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
         }
     }
+    if constexpr (NI & 1) {   // the unpaired last tile: 4 consecutive channels per lane (natural row order), 8-byte stores
+        const int ch4 = col0 + 32 * (NI / 2) + 4 * kq;
+        const float4 x0 = *(const float4*)(a.bias + ch4);
+        const float bv[4] = {x0.x, x0.y, x0.z, x0.w};
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int row = row0 + mi * 16 + lr;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { v[r] = acc[mi][NI - 1][r] + bv[r]; if (a.relu) v[r] = fmaxf(v[r], 0.f); }
+            if (row < a.rows) *(uint2*)(a.out + (size_t)row * a.out_stride + (size_t)ch4 * 2) = make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
+        }
+    }
 }
 
 template <int C>
 __global__ __launch_bounds__(256, 2) void k_conv3_duo(ConvArgs a) {
+    constexpr int kDuoRows = DuoRows<C>::value;
     extern __shared__ __attribute__((aligned(256))) char smem[];
     a.rows = live_rows(a.rows, a.np, a.rows_dev, a.board_off);
     // consecutive row tiles share halo rows: give them to one XCD (workgroup ids are dealt round-robin over the 8 XCDs and
@@ -624,6 +644,7 @@ struct PackedConv {
     size_t block_vecs = 0;
     int cin_pad = 0, cout = 0, ncols = 0, taps = 0;
     bool slab = false;   // 3x3 with activations staged through LDS (weights packed chunk-major)
+    bool duo = false;    // packed for k_conv3_duo with an odd tile count per wave (the wave's last tile unpaired)
 };
 
 struct LayerNet {
@@ -659,7 +680,10 @@ static int pack_layer(LayerNet* m, const std::vector<float>& w, const std::vecto
     for (int c0 = 0; c0 < cout; c0 += ncols) {
         const int nc = std::min(ncols, cout - c0);
         std::vector<float> sub(w.begin() + (size_t)c0 * cin * taps, w.begin() + (size_t)(c0 + nc) * cin * taps);
-        std::vector<uint16_t> pk = pack_conv(sub, nc, cin, taps, cin_pad, ncols, slab);
+        // 192 output channels in one block: k_conv3_duo, 3 tiles per wave, the third with its rows in natural channel order
+        const bool duo3 = slab && ncols == 192 && cout == 192;
+        out->duo = duo3;
+        std::vector<uint16_t> pk = pack_conv(sub, nc, cin, taps, cin_pad, ncols, slab, duo3 ? 3 : 0);
         block = pk.size() * 2 / 16;
         all.insert(all.end(), pk.begin(), pk.end());
     }
@@ -802,8 +826,9 @@ static int launch_slab(const ConvArgs& a, int cout, hipStream_t st) {
 
 template <int C>
 static int launch_duo(const ConvArgs& a, hipStream_t st) {
+    constexpr int kDuoRows = DuoRows<C>::value;
     const int row_tiles = (a.rows + kDuoRows - 1) / kDuoRows;
-    hipLaunchKernelGGL((k_conv3_duo<C>), dim3((unsigned)std::min((row_tiles + 7) / 8 * 8, kPersistGrid)), dim3(256), (size_t)kDuoLds, st, a);
+    hipLaunchKernelGGL((k_conv3_duo<C>), dim3((unsigned)std::min((row_tiles + 7) / 8 * 8, kPersistGrid)), dim3(256), (size_t)DuoGeo<kDuoRows>::kLds, st, a);
     return AZ_OK;
 }
 
@@ -817,10 +842,10 @@ static int launch_conv(const PackedConv& pc, const char* in, int zero_off, char*
     const int key = (pc.cin_pad / 32) * 1000 + pc.ncols;
     if (pc.slab && n + 1 <= kMaxHalo) {
         if (pc.ncols == 256 && pc.cout == 256) return launch_duo<256>(a, st);
+        if (pc.ncols == 192 && pc.cout == 192 && pc.duo) return launch_duo<192>(a, st);
         switch (pc.ncols) {
             case 64: return launch_slab<64>(a, pc.cout, st);
             case 128: return launch_slab<128>(a, pc.cout, st);
-            case 192: return launch_slab<192>(a, pc.cout, st);
             default: return fail(AZ_ERR_ARG, "bf16 layer path: no slab kernel for this shape");
         }
     }
