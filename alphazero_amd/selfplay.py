@@ -193,6 +193,9 @@ class _Lane:
                 self.rows_dev = self.eng.rows_device()
                 self.logits_buf = torch.empty((self.max_rows, self.A), dtype=torch.float32, device=self.dev)
                 self.values_buf = torch.empty((self.max_rows,), dtype=torch.float32, device=self.dev)
+            self.visits_h = torch.empty((self.G, self.A), dtype=torch.int32, pin_memory=True)
+            self.rv_h = torch.empty((self.G,), dtype=torch.float64, pin_memory=True)
+            self.info_np = None
             self.step_no = 0
         self.inflight = None
 
@@ -213,6 +216,7 @@ class _Lane:
         self.log_base = self.step_no         # step index of log[0]
         self.start_step = np.full(G, self.step_no, np.int64)   # first step of the game in each slot
         self.inflight = None
+        self.info_np = None
         self._open_games(np.nonzero(self.game_id >= 0)[0])
 
     def _open_games(self, slots):
@@ -251,16 +255,27 @@ class _Lane:
             return
         eng, c, cfg = self.eng, self.o.counters, self.o.cfg
         with torch.cuda.stream(self.stream):
-            _, info = eng.status()
+            if self.info_np is None:       # the first move, or games were re-dealt: finish() otherwise leaves the status here
+                self.info_np = eng.status()[1].cpu().numpy()
+            to_play = self.info_np[:, 0].copy()
             packed = self._pack_planes(eng.features(N.AZ_FEAT_F32_NCHW)) if self.o.collect else None
             eng.search_begin(torch.from_numpy(active.astype(np.uint8)))
-            rows = eng.pending()
-            to_play = info.cpu().numpy()[:, 0].copy()
-            if eng.gather_rows() == 0:
-                raise N.NativeError("search with no root")
-            feats = eng.gather(rows, self.layout, out=self.feat_buf)
-            logits, values = self.eval(feats[:rows]) if rows > 0 else (None, None)   # rows == 0: every root's logits were carried over
-            counts = eng.root_legal_counts().cpu().numpy()
+            if self.async_search:
+                # root rows: gathered and evaluated over their upper bound, so the one round trip of the root phase (the
+                # legal-move counts the noise needs) starts behind the network instead of in front of it
+                eng.gather(self.max_rows, self.layout, out=self.feat_buf)
+                self.net.forward_indirect(self.feat_buf, self.rows_dev, self.max_rows, self.logits_buf, self.values_buf)
+                counts = eng.root_legal_counts()
+                rows = eng.pending()
+                logits, values = self.logits_buf, self.values_buf
+            else:
+                rows = eng.pending()
+                if eng.gather_rows() == 0:
+                    raise N.NativeError("search with no root")
+                feats = eng.gather(rows, self.layout, out=self.feat_buf)
+                logits, values = self.eval(feats[:rows]) if rows > 0 else (None, None)   # rows == 0: every root's logits were carried over
+                counts = eng.root_legal_counts()
+            counts = counts.cpu().numpy()
             t0 = time.perf_counter()
             noise = self.rng.dirichlet(counts, cfg.dirichlet_alpha, self.A)
             c["t_host_rng"] += time.perf_counter() - t0
@@ -287,6 +302,8 @@ class _Lane:
                 else:
                     done = eng.expand(None, None)
             visits, rv = eng.result()
+            self.visits_h.copy_(visits, non_blocking=True)      # on the host by the time finish() has waited for the search
+            self.rv_h.copy_(rv, non_blocking=True)
         self.inflight = (active, to_play, packed, visits, rv)
 
     # ------------------------------------------------------------------ one move, second half (train.py:322-343)
@@ -305,7 +322,7 @@ class _Lane:
             c["sims"] += st["sims"]
             c["nn_rows_nodedup"] += st["rows_raw"]
             c["depth_sum"] += st["depth_sum"]
-            visits, rv = visits.cpu().numpy(), rv.cpu().numpy()
+            visits, rv = self.visits_h.numpy(), self.rv_h.numpy()   # az_mcts_stats has synchronised the stream
             t0 = time.perf_counter()
             temps = np.where(move_idx < cfg.temp_moves, cfg.temp_start,
                              np.where(move_idx < cfg.temp_mid_moves, cfg.temp_mid, cfg.temp_end)).astype(np.float64)
@@ -329,11 +346,15 @@ class _Lane:
                 rs = active & (np.abs(rv) >= cfg.resign_threshold) & (move_idx >= 12)
                 resigned[rs] = np.where(rv[rs] < 0, -to_play[rs], to_play[rs])
             actions[resigned != 0] = -1
-            eng.play(torch.from_numpy(actions))
+            played = eng.play(torch.from_numpy(actions), raise_on_illegal=False)
             move_idx[active & (resigned == 0)] += 1
             c["moves"] += int(active.sum())
             _, info = eng.status()
-            info = info.cpu().numpy()
+            info = torch.cat((info, played.view(-1, 1)), dim=1).cpu().numpy()      # one round trip for both
+            if info[:, 8].any():
+                g = int(np.nonzero(info[:, 8])[0][0])
+                raise ValueError(f"Illegal move: {divmod(int(actions[g]), cfg.board_size)}")
+            self.info_np = info = info[:, :8]
             over = active & ((info[:, 6] != 0) | (resigned != 0))
             if over.any():
                 reset = np.zeros(G, np.uint8)
@@ -349,6 +370,7 @@ class _Lane:
                     if gid >= 0:
                         self.rng.seed(s, o.seed0 + gid)
                         reset[s] = 1
+                self.info_np = None      # finished games keep their slot's status until re-dealt; launch() reads it again
                 if reset.any():
                     eng.reset(torch.from_numpy(reset))
                     self._open_games(np.nonzero(reset)[0])
@@ -415,6 +437,11 @@ class BatchedSelfPlay:
         """Switch between enqueueing the batches of a search without host round trips and one round trip per batch."""
         for ln in self.lanes:
             ok = bool(enable) and ln.can_async
+            if ok and not hasattr(ln, "logits_buf"):
+                with torch.cuda.stream(ln.stream):
+                    ln.rows_dev = ln.eng.rows_device()
+                    ln.logits_buf = torch.empty((ln.max_rows, ln.A), dtype=torch.float32, device=ln.dev)
+                    ln.values_buf = torch.empty((ln.max_rows,), dtype=torch.float32, device=ln.dev)
             ln.async_search = ok
             ln.eng.set_async(ok)
 
