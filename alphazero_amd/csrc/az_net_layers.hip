@@ -721,7 +721,7 @@ int layers_cap_boards(const LayerNet* m) { return m->cap_boards; }
 // in flight may still read them).
 int layers_reserve(LayerNet* m, int boards) {
     const int C = m->cfg.channels, np = m->np;
-    const int limit = (int)((((size_t)1 << 31) - kZeroTail) / ((size_t)np * C * 2)) - 1;
+    const int limit = (int)((((size_t)1 << 31) - ((size_t)1 << 20)) / ((size_t)np * C * 2)) - 1;   // 32-bit byte offsets, halo rows included
     boards = std::min(std::max(boards, m->chunk_boards), std::max(limit, m->chunk_boards));
     if (boards <= m->cap_boards) return AZ_OK;
     if (hipSetDevice(m->cfg.device) != hipSuccess) return fail(AZ_ERR_HIP, "hipSetDevice");
@@ -759,7 +759,7 @@ int layers_create(const az_net_config& c, const NetLayout& L, const float* Pm, L
     // boards per chunk: activation arrays of at most ~96 MiB each (measured at 19x19 256 channels: 32 MiB -6 %, 96-128 MiB +2 % over 64)
     m->chunk_boards = std::max(16, (int)(((size_t)96 << 20) / ((size_t)np * C * 2)));
     if (const char* e = getenv("AZ_LAYER_CHUNK_BOARDS")) {   // diagnostics: another chunk size (byte offsets stay below 2 GiB)
-        const int v = atoi(e), cap = (int)(((size_t)1 << 31) / ((size_t)np * 256 * 2)) - 1;
+        const int v = atoi(e), cap = (int)((((size_t)1 << 31) - ((size_t)1 << 20)) / ((size_t)np * C * 2)) - 1;
         if (v >= 16) m->chunk_boards = std::min(v, cap);
     }
     std::vector<float> w, b;
