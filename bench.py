@@ -39,7 +39,7 @@ WORKLOADS = {
             text="9x9 full net 192ch x 12 SE blocks, 256 sims/move, top-k 48, virtual loss 1.0, {g} lockstep games per GPU (BASELINE.json configs[2])"),
     2: dict(board=9, ch=64, blocks=4, sims=192, topk=0, games=512, lanes=2, batch=16,
             text="9x9 small net 64ch x 4 blocks, 192 sims/move, {g} lockstep games per GPU (BASELINE.json configs[1])"),
-    5: dict(board=19, ch=256, blocks=20, sims=800, topk=48, games=512, lanes=1, batch=16,
+    5: dict(board=19, ch=256, blocks=20, sims=800, topk=48, games=512, lanes=2, batch=16,
             text="19x19 256ch x 20 SE blocks, 800 sims/move, history 8, top-k 48, {g} lockstep games per GPU (per-GPU share of BASELINE.json configs[4])"),
 }
 PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak of MI355X
