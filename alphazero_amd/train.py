@@ -65,7 +65,7 @@ _SPEC = [
 # Knobs of the GPU engine that upstream has no counterpart for (kept out of upstream's field set on purpose).
 _ENGINE_SPEC = [
     ("lockstep_games", 0, "value"),      # device game slots per GPU (0: as many as the iteration has games, at most 4096)
-    ("selfplay_lanes", 0, "value"),      # independent lanes (0: 3 when a lane gets >= 256 games, else 1)
+    ("selfplay_lanes", 0, "value"),      # independent lanes (0: 4 from 2048 game slots, 3 from 768, 2 from 512, else 1)
     ("no_dedup_leaves", False, "flag"),  # evaluate a leaf reached by several descents of a batch every time, as upstream does
 ]
 UPSTREAM_FIELDS = tuple(n for n, _, _ in _SPEC)
@@ -419,7 +419,7 @@ def run_selfplay(best_model, cfg, iter_idx: int, pool=None, model_path=None, mod
     best_model.eval()
     on_gpu = next(best_model.parameters()).is_cuda
     slots = min(mine, cfg.lockstep_games if cfg.lockstep_games > 0 else 4096)
-    lanes = cfg.selfplay_lanes if cfg.selfplay_lanes > 0 else (4 if slots >= 2048 else 3 if slots >= 768 else 1)
+    lanes = cfg.selfplay_lanes if cfg.selfplay_lanes > 0 else (4 if slots >= 2048 else 3 if slots >= 768 else 2 if slots >= 512 else 1)
     sp = BatchedSelfPlay(best_model if on_gpu else _host_evaluator(best_model), SelfPlayConfig.from_train_config(cfg), games=slots,
                          seed0=selfplay_seed0(cfg, iter_idx) + first, dedup_leaves=not cfg.no_dedup_leaves, lanes=lanes,
                          tower_workgroups=1024 if lanes > 1 else None)
