@@ -284,6 +284,29 @@ def test_lockstep_selfplay_on_19x19_layer_path():
     assert logs[0][1]["nn_rows"] == logs[1][1]["nn_rows"]
 
 
+def test_lockstep_selfplay_on_13x13_fused_tower():
+    """13x13 with 192 channels: the fused tower serves the search (one 169-point board per workgroup); a few lockstep
+    moves with the batches enqueued without round trips equal the same moves with one round trip per batch."""
+    import torch
+    from alphazero_amd.model import AlphaZeroNet
+    from alphazero_amd.selfplay import BatchedSelfPlay, SelfPlayConfig
+    torch.manual_seed(8)
+    net = AlphaZeroNet(board_size=13, channels=192, num_blocks=2).eval().cuda()
+    cfg = SelfPlayConfig(board_size=13, mcts_simulations=24, mcts_inference_batch=8, mcts_topk_expand=20)
+    logs = []
+    for use_async in (True, False):
+        sp = BatchedSelfPlay(net, cfg, games=7, seed0=5)
+        assert sp.net.fused and sp.async_search
+        sp.set_async(use_async)
+        sp.begin(num_games=7)
+        for _ in range(3):
+            sp.step()
+        assert sp.counters["sims"] == 3 * 7 * 24
+        logs.append([x[2].copy() for x in sp.log])
+    for pa, pb in zip(*logs):
+        assert pa.shape == (7, 170) and np.array_equal(pa, pb)
+
+
 def test_layer_path_selfplay_row_bound_above_one_chunk_stays_asynchronous():
     """A layer-path search whose row bound (games x inference batch) is above the network's default chunk: reserving the
     bound grows the activation arrays, so the batches are still enqueued without round trips in one pass (the kernels

@@ -116,9 +116,10 @@ EXACT = [("fused", dict(board_size=9, channels=192, num_blocks=12), 40), ("fused
          ("fused", dict(board_size=9, channels=64, num_blocks=4, use_se=False), 41), ("fused", dict(board_size=5, channels=32, num_blocks=2, value_hidden_dim=64), 23),
          ("fused", dict(board_size=7, channels=128, num_blocks=3, history_len=4), 17), ("fused", dict(board_size=6, channels=192, num_blocks=2), 15),
          ("fused", dict(board_size=5, channels=192, num_blocks=2, value_hidden_dim=64), 30),
+         ("fused", dict(board_size=13, channels=192, num_blocks=2), 7), ("fused", dict(board_size=13, channels=192, num_blocks=1, use_se=False, history_len=4), 2),
          ("layers", dict(board_size=13, channels=64, num_blocks=2), 5), ("layers", dict(board_size=19, channels=128, num_blocks=2), 4),
          ("layers", dict(board_size=19, channels=256, num_blocks=3), 3), ("layers", dict(board_size=9, channels=256, num_blocks=2, value_hidden_dim=64), 9),
-         ("layers", dict(board_size=13, channels=192, num_blocks=2), 7), ("layers", dict(board_size=19, channels=192, num_blocks=2, history_len=4), 5)]
+         ("layers", dict(board_size=11, channels=192, num_blocks=2), 7), ("layers", dict(board_size=19, channels=192, num_blocks=2, history_len=4), 5)]
 
 
 @pytest.mark.parametrize("small", ["small_variant", "two_per_cu_kernel", "256_row_kernel"])
@@ -135,8 +136,8 @@ def test_bf16_exact_integer_network(path, kw, rows, small, monkeypatch):
         monkeypatch.setenv("AZ_TOWER_SMALL", "0")       # few rows would otherwise all go through the 96-row variant
         if small == "256_row_kernel":
             monkeypatch.setenv("AZ_TOWER_DUO", "0")     # 192 channels on 9x9 / 5x5 otherwise run two 176-row workgroups per CU
-        elif kw["channels"] != 192 or kw["board_size"] not in (5, 9):
-            pytest.skip("the two-workgroups-per-CU kernel serves 192 channels on 9x9 and 5x5")
+        elif kw["channels"] != 192 or kw["board_size"] not in (5, 9, 13):
+            pytest.skip("the two-workgroups-per-CU kernel serves 192 channels on 13x13, 9x9 and 5x5")
     net, x, lg_want, v_want = exactnet.find_exact_net(kw, path, rows)
     dev = torch.device("cuda:0")
     nn = net.to(dev).native("bf16", shared=False)
@@ -255,6 +256,48 @@ def test_bf16_layer_path(kw):
     assert torch.equal(lg[perm], lg_p) and torch.equal(v[perm], v_p)
     lg_1, v_1 = nn(f[4:5].contiguous())
     assert torch.equal(lg[4:5], lg_1) and torch.equal(v[4:5], v_1)
+
+
+def test_fused_tower_on_13x13(monkeypatch):
+    """13x13 with 192 channels runs the fused tower (one board of 169 points per two-per-CU workgroup): within 1e-2 of
+    the float32 torch module on default-initialised weights, a position's output independent of its neighbours in the
+    batch and of the kernel (two-per-CU or 256-row), and close to what the layer-by-layer path gives for the same weights
+    (AZ_NO_FUSED_13=1; another summation order, so not the same bits)."""
+    from alphazero_amd.model import AlphaZeroNet
+    import stubnets
+    torch.manual_seed(13)
+    net = AlphaZeroNet(board_size=13, channels=192, num_blocks=3).eval()
+    x = stubnets.synthetic_planes(21, 21, 13, seed=4)
+    with torch.inference_mode():
+        lg_t, v_t = net(torch.from_numpy(x))
+    dev = torch.device("cuda:0")
+    net = net.to(dev)
+    nn = net.native("bf16", shared=False)
+    assert nn.fused
+    f = _to_nhwc_bf16(x).to(dev)
+    lg, v = nn(f)
+    assert float((lg.cpu() - lg_t).abs().max()) <= 1e-2 and float((v.cpu() - v_t).abs().max()) <= 1e-2
+    perm = torch.randperm(21)
+    lg_p, v_p = nn(f[perm].contiguous())
+    assert torch.equal(lg[perm], lg_p) and torch.equal(v[perm], v_p)
+    lg_1, v_1 = nn(f[9:10].contiguous())
+    assert torch.equal(lg[9:10], lg_1) and torch.equal(v[9:10], v_1)
+    monkeypatch.setenv("AZ_TOWER_DUO", "0")
+    nn256 = net.native("bf16", shared=False)
+    monkeypatch.delenv("AZ_TOWER_DUO")
+    lg_256, v_256 = nn256(f)
+    assert torch.equal(lg_256, lg) and torch.equal(v_256, v)
+    monkeypatch.setenv("AZ_NO_FUSED_13", "1")
+    nnl = net.native("bf16", shared=False)
+    monkeypatch.delenv("AZ_NO_FUSED_13")
+    assert not nnl.fused
+    lg_l, v_l = nnl(f)
+    assert float((lg_l - lg).abs().max()) <= 2e-3 and float((v_l - v).abs().max()) <= 2e-3
+    rows_dev = torch.tensor([13], dtype=torch.int32, device=dev)
+    lb = torch.full((21, 170), -7.0, dtype=torch.float32, device=dev)
+    vb = torch.full((21,), -7.0, dtype=torch.float32, device=dev)
+    nn.forward_indirect(f, rows_dev.data_ptr(), 21, lb, vb)
+    assert torch.equal(lb[:13], lg[:13]) and torch.equal(vb[:13], v[:13]) and bool((lb[13:] == -7.0).all())
 
 
 @pytest.mark.parametrize("channels", [64, 256])
