@@ -1,5 +1,5 @@
 // bf16 MFMA inference of the policy/value tower (model.py:43-97, eval mode) layer by layer, for the shapes
-// whose activations do not fit one workgroup's LDS (boards above 9x9 other than 13x13 x 192 channels; 256 channels): every convolution is one
+// whose activations do not fit one workgroup's LDS (boards above 9x9 other than 11x11 to 13x13 with 192 channels; 256 channels): every convolution is one
 // launch, an implicit GEMM over all boards of a chunk on v_mfma_f32_16x16x32_bf16 with the weight tiles
 // double-buffered in LDS like in the fused tower (az_mfma_gemm.cuh). The 3x3 convolutions (k_conv3_slab) stage
 // the bf16 [position][channel] activations through LDS slabs; the 1x1 head (k_conv_layer) reads them from L2. The

@@ -795,10 +795,16 @@ static int up(MfmaNet* m, const std::vector<T>& v, T** out) {
     return AZ_OK;
 }
 
+// Whether whole boards fill the 176 rows of a two-per-CU workgroup well enough: 90 % where the 256-row kernel is the
+// alternative (9x9: 162 rows, 5x5: 175); 65 % for boards of more than 88 points, whose alternative is the layer-by-layer
+// path (measured at 192 channels x 12 blocks, 1024 boards, fused against layer path: 13x13 1 255 / 793 TFLOP/s at 96 %,
+// 12x12 1 095 / 899 at 82 %, 11x11 957 / 890 at 69 %, 10x10 817 / 807 at 57 %).
+static bool duo_fill_ok(int np) { return np <= 176 && (176 / np) * np * 100 >= 176 * (np > 88 ? 65 : 90); }
+
 static bool fused_supported(const az_net_config& c) {
     const bool cok = c.channels == 32 || c.channels == 64 || c.channels == 128 || c.channels == 192;
-    // 13x13 with 192 channels: one board (169 points) fills 96 % of the 176 rows of a two-per-CU workgroup
-    const bool bok = c.board_size <= 9 || (c.board_size == 13 && c.channels == 192 && !getenv("AZ_NO_FUSED_13"));
+    // above 9x9: 192 channels where one board fills the 176 rows of a two-per-CU workgroup well enough (11x11 to 13x13)
+    const bool bok = c.board_size <= 9 || (c.channels == 192 && duo_fill_ok(c.board_size * c.board_size) && !getenv("AZ_NO_FUSED_13"));
     return cok && bok && c.board_size >= 2 && c.in_planes <= 64;
 }
 bool mfma_supported(const az_net_config& c) { return (fused_supported(c) || layers_supported(c)) && c.value_hidden >= 1; }
@@ -846,8 +852,8 @@ int mfma_create(const az_net_config& c, const NetLayout& L, const float* Pm, Mfm
     m->TB_small = (fused && m->split == 1 && (C == 128 || C == 192) && np <= 96) ? 96 / np : 0;
     if (const char* sm = getenv("AZ_TOWER_SMALL")) if (atoi(sm) == 0) m->TB_small = 0;
     // two 256-thread workgroups of two boards per compute unit (192 channels, global-weights form)
-    // where whole boards fill at least 90 % of its 176 rows (9x9: 162, 5x5: 175, 13x13: 169); AZ_TOWER_DUO=0 switches it off
-    m->TB_duo = (fused && m->split == 1 && C == 192 && np <= 176 && (176 / np) * np * 10 >= 176 * 9) ? 176 / np : 0;
+    // where whole boards fill at least 90 % of its 176 rows (duo_fill_ok); AZ_TOWER_DUO=0 switches it off
+    m->TB_duo = (fused && m->split == 1 && C == 192 && duo_fill_ok(np)) ? 176 / np : 0;
     if (const char* du = getenv("AZ_TOWER_DUO")) if (atoi(du) == 0) m->TB_duo = 0;
     const int tiles_per_wave = C / 64;              // 2x4 waves: C/4 channels each
     const int slab_tiles = (m->split == 1 && (tiles_per_wave & 1)) ? tiles_per_wave : 0;   // channel tiles per wave when that count is odd
@@ -1382,7 +1388,7 @@ long long mfma_static_max_rows(const MfmaNet* m) {
 }
 
 int mfma_forward_static(MfmaNet* m, const void* feat, int rows, float* logits, float* values, hipStream_t st) {
-    if (m->layers) return fail(AZ_ERR_ARG, "az_net_forward_static: fused bf16 networks only (boards up to 9x9 with up to 192 channels, 13x13 with 192)");
+    if (m->layers) return fail(AZ_ERR_ARG, "az_net_forward_static: fused bf16 networks only (boards up to 9x9 with up to 192 channels, 11x11 to 13x13 with 192)");
     const long long cap = mfma_static_max_rows(m);
     if (rows > cap)
         return fail(AZ_ERR_CAPACITY, "az_net_forward_static: " + std::to_string(rows) + " rows exceed the static scratch (at most " +

@@ -182,7 +182,7 @@ int az_net_forward(az_net* net, const void* feat_dev, int32_t rows, float* logit
  * as the lazily built torch workspace behind model(x) in mcts.py:59-64. */
 int az_net_reserve(az_net* net, int32_t rows);
 
-/* *fused = 1 if the bf16 network runs as the single fused tower kernel (boards up to 9x9 with up to 192 channels; 13x13 with 192 channels), 0 if
+/* *fused = 1 if the bf16 network runs as the single fused tower kernel (boards up to 9x9 with up to 192 channels; 11x11 to 13x13 with 192 channels), 0 if
  * it runs layer by layer (larger boards, 256 channels) or in float32. */
 int az_net_is_fused(az_net* net, int32_t* fused);
 /* az_net_forward with the row count read on the device from *rows_dev (<= max_rows): no host round trip. bf16

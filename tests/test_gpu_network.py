@@ -117,9 +117,10 @@ EXACT = [("fused", dict(board_size=9, channels=192, num_blocks=12), 40), ("fused
          ("fused", dict(board_size=7, channels=128, num_blocks=3, history_len=4), 17), ("fused", dict(board_size=6, channels=192, num_blocks=2), 15),
          ("fused", dict(board_size=5, channels=192, num_blocks=2, value_hidden_dim=64), 30),
          ("fused", dict(board_size=13, channels=192, num_blocks=2), 7), ("fused", dict(board_size=13, channels=192, num_blocks=1, use_se=False, history_len=4), 2),
+         ("fused", dict(board_size=11, channels=192, num_blocks=2), 6), ("fused", dict(board_size=12, channels=192, num_blocks=2), 5),
          ("layers", dict(board_size=13, channels=64, num_blocks=2), 5), ("layers", dict(board_size=19, channels=128, num_blocks=2), 4),
          ("layers", dict(board_size=19, channels=256, num_blocks=3), 3), ("layers", dict(board_size=9, channels=256, num_blocks=2, value_hidden_dim=64), 9),
-         ("layers", dict(board_size=11, channels=192, num_blocks=2), 7), ("layers", dict(board_size=19, channels=192, num_blocks=2, history_len=4), 5)]
+         ("layers", dict(board_size=10, channels=192, num_blocks=2), 7), ("layers", dict(board_size=19, channels=192, num_blocks=2, history_len=4), 5)]
 
 
 @pytest.mark.parametrize("small", ["small_variant", "two_per_cu_kernel", "256_row_kernel"])
@@ -136,8 +137,8 @@ def test_bf16_exact_integer_network(path, kw, rows, small, monkeypatch):
         monkeypatch.setenv("AZ_TOWER_SMALL", "0")       # few rows would otherwise all go through the 96-row variant
         if small == "256_row_kernel":
             monkeypatch.setenv("AZ_TOWER_DUO", "0")     # 192 channels on 9x9 / 5x5 otherwise run two 176-row workgroups per CU
-        elif kw["channels"] != 192 or kw["board_size"] not in (5, 9, 13):
-            pytest.skip("the two-workgroups-per-CU kernel serves 192 channels on 13x13, 9x9 and 5x5")
+        elif kw["channels"] != 192 or kw["board_size"] not in (5, 9, 11, 12, 13):
+            pytest.skip("the two-workgroups-per-CU kernel serves 192 channels on 11x11 to 13x13, 9x9 and 5x5")
     net, x, lg_want, v_want = exactnet.find_exact_net(kw, path, rows)
     dev = torch.device("cuda:0")
     nn = net.to(dev).native("bf16", shared=False)
