@@ -776,6 +776,7 @@ struct MfmaNet {
                                   // them, so they are only freed with the network (sizes grow geometrically: bounded waste)
     int TB_duo = 0;               // boards per workgroup of the two-workgroups-per-CU variant (176 rows, 256 threads; 0: none)
     int TB_small = 0;             // boards per workgroup of the 96-row low-latency variant (0: this shape has none)
+    int rows_main = 256;          // rows of the main kernel's workgroup: 256, or 384 for one board of 17x17 to 19x19 (128 channels)
     int split = 0;                // 0: 4x2 waves, weights through LDS; 1: 2x4 waves, weight fragments from global memory (C = 192)
     LayerNet* layers = nullptr;   // set instead of the fused tower's weights when the shape needs the layer-by-layer path
     // optional timing of the tower kernel with HIP events on the launch stream
@@ -804,7 +805,10 @@ static bool duo_fill_ok(int np) { return np <= 176 && (176 / np) * np * 100 >= 1
 static bool fused_supported(const az_net_config& c) {
     const bool cok = c.channels == 32 || c.channels == 64 || c.channels == 128 || c.channels == 192;
     // above 9x9: 192 channels where one board fills the 176 rows of a two-per-CU workgroup well enough (11x11 to 13x13)
-    const bool bok = c.board_size <= 9 || (c.channels == 192 && duo_fill_ok(c.board_size * c.board_size) && !getenv("AZ_NO_FUSED_13"));
+    // 17x17 to 19x19: 128 channels, one board in a 384-row workgroup (its activation image, 108 KB, still fits the LDS)
+    const int np = c.board_size * c.board_size;
+    const bool bok = c.board_size <= 9 || (c.channels == 192 && duo_fill_ok(np) && !getenv("AZ_NO_FUSED_13")) ||
+                     (c.channels == 128 && np > 256 && np <= 384 && np * 4 >= 384 * 3 && !getenv("AZ_NO_FUSED_19"));
     return cok && bok && c.board_size >= 2 && c.in_planes <= 64;
 }
 bool mfma_supported(const az_net_config& c) { return (fused_supported(c) || layers_supported(c)) && c.value_hidden >= 1; }
@@ -812,8 +816,8 @@ bool mfma_is_fused(const MfmaNet* m) { return m->layers == nullptr; }
 
 // Residual scratch for `workgroups` resident workgroups of the 256-row kernel; the two-per-CU variant runs twice as many
 // workgroups of 17 x 256 vectors each out of the same buffer.
-static size_t xres_bytes(int workgroups, int C, bool duo) {
-    const size_t per = (size_t)256 * C * 2, per_duo = (size_t)2 * 17 * 256 * 16;
+static size_t xres_bytes(int workgroups, int C, bool duo, int rows_main = 256) {
+    const size_t per = (size_t)rows_main * C * 2, per_duo = (size_t)2 * 17 * 256 * 16;
     return (size_t)workgroups * std::max(per, duo ? per_duo : (size_t)0);
 }
 
@@ -840,13 +844,15 @@ int mfma_create(const az_net_config& c, const NetLayout& L, const float* Pm, Mfm
     MfmaNet* m = new MfmaNet();
     m->cfg = c;
     const int C = c.channels, np = c.board_size * c.board_size, q = C / 4, A = np + 1;
-    m->TB = 256 / np;
+    m->rows_main = np > 256 ? 384 : 256;
+    m->TB = m->rows_main / np;
     m->cin_pad = c.in_planes <= 32 ? 32 : 64;
     m->q = q;
     m->NH = std::max(32, 2 * q);   // policy q + value q channels, in whole tile pairs
     const bool fused = fused_supported(c);
     m->split = C >= 128 ? 1 : 0;   // measured: 192 ch +3 %, 128 ch +5 %, 64 ch -3 %
     if (const char* sp = getenv("AZ_TOWER_SPLIT")) m->split = (C >= 64 && atoi(sp) == 1) ? 1 : 0;   // 0 selects the LDS-staged variant
+    if (m->rows_main == 384) m->split = 1;   // the 384-row kernel exists in the global-weights form only
     // the 96-row variant shares the 2x4-wave kernels' weight images: 128 / 192 channels in their default (global-weights)
     // form, boards of at most 96 points; AZ_TOWER_SMALL=0 switches it off
     m->TB_small = (fused && m->split == 1 && (C == 128 || C == 192) && np <= 96) ? 96 / np : 0;
@@ -857,7 +863,7 @@ int mfma_create(const az_net_config& c, const NetLayout& L, const float* Pm, Mfm
     if (const char* du = getenv("AZ_TOWER_DUO")) if (atoi(du) == 0) m->TB_duo = 0;
     const int tiles_per_wave = C / 64;              // 2x4 waves: C/4 channels each
     const int slab_tiles = (m->split == 1 && (tiles_per_wave & 1)) ? tiles_per_wave : 0;   // channel tiles per wave when that count is odd
-    if (fused && tower_lds_bytes(C, m->NH, m->TB, c.se_hidden) > 160 * 1024) { delete m; return fail(AZ_ERR_ARG, "bf16 MFMA path: LDS budget exceeded"); }
+    if (fused && tower_lds_bytes(C, m->NH, m->TB, c.se_hidden, m->rows_main) > 160 * 1024) { delete m; return fail(AZ_ERR_ARG, "bf16 MFMA path: LDS budget exceeded"); }
     std::vector<float> w, b;
     TowerParams& P = m->P;
     memset(&P, 0, sizeof(P));
@@ -974,7 +980,7 @@ int mfma_create(const az_net_config& c, const NetLayout& L, const float* Pm, Mfm
     }
 #undef TRY
     // opt in to the large dynamic LDS size once
-    const size_t lds = fused ? tower_lds_bytes(C, m->NH, m->TB, c.se_hidden) : 0;
+    const size_t lds = fused ? tower_lds_bytes(C, m->NH, m->TB, c.se_hidden, m->rows_main) : 0;
     hipError_t e = hipSuccess;
     switch (fused ? C : 0) {
         case 32: e = hipFuncSetAttribute((const void*)k_tower<32, 8, 1, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); break;
@@ -988,6 +994,8 @@ int mfma_create(const az_net_config& c, const NetLayout& L, const float* Pm, Mfm
             if (e == hipSuccess && m->TB_small)
                 e = hipFuncSetAttribute((const void*)k_tower<128, 2, 4, 64, 1, 96>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)tower_lds_bytes(C, m->NH, m->TB_small, c.se_hidden, 96));
+            if (e == hipSuccess && m->rows_main == 384)
+                e = hipFuncSetAttribute((const void*)k_tower<128, 2, 4, 64, 1, 384>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             break;
         case 192:
             e = hipFuncSetAttribute((const void*)k_tower<192, 4, 2, 96>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1011,7 +1019,7 @@ int mfma_create(const az_net_config& c, const NetLayout& L, const float* Pm, Mfm
         if (hipGetDeviceProperties(&prop, c.device) != hipSuccess) { mfma_destroy(m); return fail(AZ_ERR_HIP, "hipGetDeviceProperties"); }
         m->max_grid = std::max(1, prop.multiProcessorCount);
         m->cus = m->max_grid;
-        if (hipMalloc((void**)&m->xres, xres_bytes(m->max_grid, C, m->TB_duo > 0)) != hipSuccess) { mfma_destroy(m); return fail(AZ_ERR_HIP, "hipMalloc (residual scratch)"); }
+        if (hipMalloc((void**)&m->xres, xres_bytes(m->max_grid, C, m->TB_duo > 0, m->rows_main)) != hipSuccess) { mfma_destroy(m); return fail(AZ_ERR_HIP, "hipMalloc (residual scratch)"); }
     } else {   // layer path: head activations (and value-tail shares) of one chunk, sized once
         int rcr = mfma_reserve(m, layers_chunk_boards(m->layers));
         if (rcr != AZ_OK) { mfma_destroy(m); return rcr; }
@@ -1035,7 +1043,7 @@ int mfma_reserve(MfmaNet* m, int rows) {
     uint16_t* h = nullptr;
     if (hipMalloc((void**)&h, (size_t)rows * np * 2 * m->q * 2) != hipSuccess) return fail(AZ_ERR_HIP, "hipMalloc (head scratch)");
     float* vp = nullptr;
-    if (m->layers && np > 81 && m->w4p && m->v_ntiles > 4) {   // split value tail (run_tails)
+    if (np > 81 && m->w4p && m->v_ntiles > 4) {   // split value tail (run_tails)
         if (hipMalloc((void**)&vp, (size_t)(rows + 16) * ((m->v_ntiles + 3) / 4) * sizeof(float)) != hipSuccess) {
             (void)hipFree(h);
             return fail(AZ_ERR_HIP, "hipMalloc (value tail scratch)");
@@ -1071,7 +1079,7 @@ int mfma_set_grid_limit(MfmaNet* m, int workgroups) {
     if (workgroups == m->max_grid) return AZ_OK;
     if (hipSetDevice(m->cfg.device) != hipSuccess) return fail(AZ_ERR_HIP, "hipSetDevice");
     uint4* x = nullptr;
-    if (hipMalloc((void**)&x, xres_bytes(workgroups, m->cfg.channels, m->TB_duo > 0)) != hipSuccess) return fail(AZ_ERR_HIP, "hipMalloc (residual scratch)");
+    if (hipMalloc((void**)&x, xres_bytes(workgroups, m->cfg.channels, m->TB_duo > 0, m->rows_main)) != hipSuccess) return fail(AZ_ERR_HIP, "hipMalloc (residual scratch)");
     if (m->xres) m->retired.push_back(m->xres);
     m->xres = x;
     m->max_grid = workgroups;
@@ -1232,7 +1240,7 @@ static int fused_forward(MfmaNet* m, const void* feat, int rows, const int* rows
     }
     P.stamps = stamp_dev;
 #endif
-    const size_t lds = tower_lds_bytes(C, m->NH, TB, c.se_hidden, small ? 96 : duo ? 176 : 256, duo);
+    const size_t lds = tower_lds_bytes(C, m->NH, TB, c.se_hidden, small ? 96 : duo ? 176 : m->rows_main, duo);
     std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
     if (timed) {
         int rcp = prof_begin(m, rows_dev ? 0 : rows, st, &ev);   // indirect launches: the caller knows the row total
@@ -1246,6 +1254,7 @@ static int fused_forward(MfmaNet* m, const void* feat, int rows, const int* rows
             break;
         case 128:
             if (small) hipLaunchKernelGGL((k_tower<128, 2, 4, 64, 1, 96>), dim3(grid), dim3(512), lds, st, P);
+            else if (m->rows_main == 384) hipLaunchKernelGGL((k_tower<128, 2, 4, 64, 1, 384>), dim3(grid), dim3(512), lds, st, P);
             else if (m->split == 1) hipLaunchKernelGGL((k_tower<128, 2, 4, 64, 1>), dim3(grid), dim3(512), lds, st, P);
             else hipLaunchKernelGGL((k_tower<128, 4, 2, 64>), dim3(grid), dim3(512), lds, st, P);
             break;
@@ -1382,13 +1391,13 @@ static int static_scratch(int device, unsigned char** out) {
 static size_t static_xres_bytes(const MfmaNet* m) { return (size_t)kStaticGrid * 256 * (size_t)m->cfg.channels * 2; }
 
 long long mfma_static_max_rows(const MfmaNet* m) {
-    if (m->layers) return 0;
+    if (m->layers || m->cfg.board_size > 9) return 0;   // larger boards: other workgroup sizes and a value tail with scratch of its own
     const size_t np = (size_t)m->cfg.board_size * m->cfg.board_size;
     return (long long)((kStaticBytes - static_xres_bytes(m)) / (np * 2 * m->q * 2));
 }
 
 int mfma_forward_static(MfmaNet* m, const void* feat, int rows, float* logits, float* values, hipStream_t st) {
-    if (m->layers) return fail(AZ_ERR_ARG, "az_net_forward_static: fused bf16 networks only (boards up to 9x9 with up to 192 channels, 11x11 to 13x13 with 192)");
+    if (m->layers || m->cfg.board_size > 9) return fail(AZ_ERR_ARG, "az_net_forward_static: fused bf16 networks on boards up to 9x9 only");
     const long long cap = mfma_static_max_rows(m);
     if (rows > cap)
         return fail(AZ_ERR_CAPACITY, "az_net_forward_static: " + std::to_string(rows) + " rows exceed the static scratch (at most " +

@@ -182,7 +182,7 @@ int az_net_forward(az_net* net, const void* feat_dev, int32_t rows, float* logit
  * as the lazily built torch workspace behind model(x) in mcts.py:59-64. */
 int az_net_reserve(az_net* net, int32_t rows);
 
-/* *fused = 1 if the bf16 network runs as the single fused tower kernel (boards up to 9x9 with up to 192 channels; 11x11 to 13x13 with 192 channels), 0 if
+/* *fused = 1 if the bf16 network runs as the single fused tower kernel (boards up to 9x9 with up to 192 channels; 11x11 to 13x13 with 192 channels; 17x17 to 19x19 with 128 channels), 0 if
  * it runs layer by layer (larger boards, 256 channels) or in float32. */
 int az_net_is_fused(az_net* net, int32_t* fused);
 /* az_net_forward with the row count read on the device from *rows_dev (<= max_rows): no host round trip. bf16
@@ -190,7 +190,8 @@ int az_net_is_fused(az_net* net, int32_t* fused);
 int az_net_forward_indirect(az_net* net, const void* feat_dev, const int32_t* rows_dev, int32_t max_rows,
                             float* logits_dev, float* values_dev, void* stream);
 /* az_net_forward for callers that cannot allocate device memory (code under HIP graph capture, tight serving
- * loops, harnesses that forbid hipMalloc): no counterpart upstream. Fused bf16 networks only. The activation
+ * loops, harnesses that forbid hipMalloc): no counterpart upstream. Fused bf16 networks on boards up to 9x9 only (az_net_static_max_rows is 0
+ * for the others). The activation
  * scratch is a 64 MiB device array inside the library (one copy per GPU, held until the process ends): residual
  * stream for 256 workgroups, then the head activations, which bounds `rows` by az_net_static_max_rows (2 697 rows
  * for 9x9 / 192 channels); more rows return AZ_ERR_CAPACITY. The call allocates and frees nothing and records no

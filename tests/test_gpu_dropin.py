@@ -284,15 +284,17 @@ def test_lockstep_selfplay_on_19x19_layer_path():
     assert logs[0][1]["nn_rows"] == logs[1][1]["nn_rows"]
 
 
-def test_lockstep_selfplay_on_13x13_fused_tower():
-    """13x13 with 192 channels: the fused tower serves the search (one 169-point board per workgroup); a few lockstep
-    moves with the batches enqueued without round trips equal the same moves with one round trip per batch."""
+@pytest.mark.parametrize("n,channels", [(13, 192), (19, 128)])
+def test_lockstep_selfplay_on_large_board_fused_tower(n, channels):
+    """13x13 with 192 channels and 19x19 with 128: the fused tower serves the search (one board per workgroup of 176 or
+    384 rows); a few lockstep moves with the batches enqueued without round trips equal the same moves with one round
+    trip per batch."""
     import torch
     from alphazero_amd.model import AlphaZeroNet
     from alphazero_amd.selfplay import BatchedSelfPlay, SelfPlayConfig
     torch.manual_seed(8)
-    net = AlphaZeroNet(board_size=13, channels=192, num_blocks=2).eval().cuda()
-    cfg = SelfPlayConfig(board_size=13, mcts_simulations=24, mcts_inference_batch=8, mcts_topk_expand=20)
+    net = AlphaZeroNet(board_size=n, channels=channels, num_blocks=2).eval().cuda()
+    cfg = SelfPlayConfig(board_size=n, mcts_simulations=24, mcts_inference_batch=8, mcts_topk_expand=20)
     logs = []
     for use_async in (True, False):
         sp = BatchedSelfPlay(net, cfg, games=7, seed0=5)
@@ -304,7 +306,7 @@ def test_lockstep_selfplay_on_13x13_fused_tower():
         assert sp.counters["sims"] == 3 * 7 * 24
         logs.append([x[2].copy() for x in sp.log])
     for pa, pb in zip(*logs):
-        assert pa.shape == (7, 170) and np.array_equal(pa, pb)
+        assert pa.shape == (7, n * n + 1) and np.array_equal(pa, pb)
 
 
 def test_layer_path_selfplay_row_bound_above_one_chunk_stays_asynchronous():

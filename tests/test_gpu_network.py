@@ -118,7 +118,8 @@ EXACT = [("fused", dict(board_size=9, channels=192, num_blocks=12), 40), ("fused
          ("fused", dict(board_size=5, channels=192, num_blocks=2, value_hidden_dim=64), 30),
          ("fused", dict(board_size=13, channels=192, num_blocks=2), 7), ("fused", dict(board_size=13, channels=192, num_blocks=1, use_se=False, history_len=4), 2),
          ("fused", dict(board_size=11, channels=192, num_blocks=2), 6), ("fused", dict(board_size=12, channels=192, num_blocks=2), 5),
-         ("layers", dict(board_size=13, channels=64, num_blocks=2), 5), ("layers", dict(board_size=19, channels=128, num_blocks=2), 4),
+         ("fused", dict(board_size=19, channels=128, num_blocks=2), 4), ("fused", dict(board_size=17, channels=128, num_blocks=2, use_se=False), 3),
+         ("layers", dict(board_size=13, channels=64, num_blocks=2), 5), ("layers", dict(board_size=15, channels=128, num_blocks=2), 4),
          ("layers", dict(board_size=19, channels=256, num_blocks=3), 3), ("layers", dict(board_size=9, channels=256, num_blocks=2, value_hidden_dim=64), 9),
          ("layers", dict(board_size=10, channels=192, num_blocks=2), 7), ("layers", dict(board_size=19, channels=192, num_blocks=2, history_len=4), 5)]
 
@@ -226,7 +227,7 @@ def test_unsupported_bf16_shape_is_refused():
         net.native("bf16")
 
 
-LAYERED = [dict(board_size=13, channels=64, num_blocks=2), dict(board_size=19, channels=128, num_blocks=2),
+LAYERED = [dict(board_size=13, channels=64, num_blocks=2), dict(board_size=15, channels=128, num_blocks=2),
            dict(board_size=9, channels=256, num_blocks=2, value_hidden_dim=64),
            dict(board_size=19, channels=256, num_blocks=1, use_se=False), dict(board_size=19, channels=192, num_blocks=1, history_len=4)]
 
@@ -257,6 +258,44 @@ def test_bf16_layer_path(kw):
     assert torch.equal(lg[perm], lg_p) and torch.equal(v[perm], v_p)
     lg_1, v_1 = nn(f[4:5].contiguous())
     assert torch.equal(lg[4:5], lg_1) and torch.equal(v[4:5], v_1)
+
+
+def test_fused_tower_on_19x19_128_channels(monkeypatch):
+    """19x19 (also 17x17, 18x18) with 128 channels runs the fused tower with one board per 384-row workgroup: within 1e-2
+    of the float32 torch module, batch-invariant, close to the layer-by-layer path (AZ_NO_FUSED_19=1), and the indirect
+    forward equals the direct one."""
+    from alphazero_amd.model import AlphaZeroNet
+    import stubnets
+    torch.manual_seed(19)
+    net = AlphaZeroNet(board_size=19, channels=128, num_blocks=3).eval()
+    x = stubnets.synthetic_planes(11, 21, 19, seed=6)
+    with torch.inference_mode():
+        lg_t, v_t = net(torch.from_numpy(x))
+    dev = torch.device("cuda:0")
+    net = net.to(dev)
+    nn = net.native("bf16", shared=False)
+    assert nn.fused
+    f = _to_nhwc_bf16(x).to(dev)
+    lg, v = nn(f)
+    assert float((lg.cpu() - lg_t).abs().max()) <= 1e-2 and float((v.cpu() - v_t).abs().max()) <= 1e-2
+    perm = torch.randperm(11)
+    lg_p, v_p = nn(f[perm].contiguous())
+    assert torch.equal(lg[perm], lg_p) and torch.equal(v[perm], v_p)
+    lg_1, v_1 = nn(f[5:6].contiguous())
+    assert torch.equal(lg[5:6], lg_1) and torch.equal(v[5:6], v_1)
+    monkeypatch.setenv("AZ_NO_FUSED_19", "1")
+    nnl = net.native("bf16", shared=False)
+    monkeypatch.delenv("AZ_NO_FUSED_19")
+    assert not nnl.fused
+    lg_l, v_l = nnl(f)
+    assert float((lg_l - lg).abs().max()) <= 2e-3 and float((v_l - v).abs().max()) <= 2e-3
+    rows_dev = torch.tensor([7], dtype=torch.int32, device=dev)
+    lb = torch.full((11, 362), -7.0, dtype=torch.float32, device=dev)
+    vb = torch.full((11,), -7.0, dtype=torch.float32, device=dev)
+    nn.forward_indirect(f, rows_dev.data_ptr(), 11, lb, vb)
+    assert torch.equal(lb[:7], lg[:7]) and torch.equal(vb[:7], v[:7]) and bool((lb[7:] == -7.0).all())
+    with pytest.raises(Exception):
+        nn.forward_static(f, lb, vb)        # the entry point without allocations serves boards up to 9x9
 
 
 def test_fused_tower_on_13x13(monkeypatch):
