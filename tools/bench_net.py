@@ -10,7 +10,8 @@ def main():
     blocks = int(sys.argv[3]) if len(sys.argv) > 3 else 12
     n = int(sys.argv[4]) if len(sys.argv) > 4 else 9
     torch.manual_seed(0)
-    net = AlphaZeroNet(board_size=n, channels=ch, num_blocks=blocks).eval().to("cuda:0")
+    use_se = not (len(sys.argv) > 5 and sys.argv[5] == "nose")      # fifth argument "nose": no squeeze-excite
+    net = AlphaZeroNet(board_size=n, channels=ch, num_blocks=blocks, use_se=use_se).eval().to("cuda:0")
     nn = net.native("bf16")
     if __import__("os").environ.get("AZ_BENCH_GRID"):   # limit the resident workgroups (diagnostics)
         nn.set_tower_workgroups(int(__import__("os").environ["AZ_BENCH_GRID"]))
