@@ -74,6 +74,26 @@ def test_selfplay_game_with_opening_book():
     assert sp.lanes[0].move_idx[0] == 3
 
 
+def test_off_list_shapes_run_on_the_float32_kernels():
+    """Shapes upstream's CLI accepts but the MFMA kernels do not cover (48 channels; 13x13 with 32 channels) go through
+    native("f32") in self-play and in the arena instead of raising: same search, same games as a host evaluation of
+    the module would give is not asserted here (float32 kernels against torch are covered by the network tests), only
+    that the run completes on the native float32 path with whole games."""
+    from alphazero_amd import train as T
+    for kw in (dict(channels=48), dict(board_size=13, channels=32, mcts_simulations=4, eval_simulations=4)):
+        cfg = tiny_cfg(seed=3, selfplay_games_per_iter=2, **kw)
+        model = tiny_model(cfg, 21).cuda()
+        assert model.native_auto("cuda").precision == "f32"
+        samples, bw, ww, dd = T.run_selfplay(model, cfg, iter_idx=0)
+        assert bw + ww + dd == 2 and len(samples) > 0
+        n = cfg.board_size
+        assert samples[0][0].shape == (21, n, n) and samples[0][1].shape == (n * n + 1,)
+        assert abs(float(samples[0][1].sum()) - 1.0) < 1e-5
+        other = tiny_model(cfg, 22).cuda()
+        w, l, d = T.play_match(model, other, cfg, 2)
+        assert w + l + d == 2
+
+
 def test_device_batch_assembly_equals_host_sampling():
     from alphazero_amd import train as T
     buf = T.ReplayBuffer(capacity=50)

@@ -11,4 +11,4 @@ python3 $R/tools/pmc_tower.py $(find /tmp/pmc_a -name "*counter_collection.csv" 
 export AZ_TOWER_DUO=0
 timeout -s KILL 120 rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/pmc_b -- python3 $R/tools/bench_net.py 4096 192 12 9 > /tmp/pmc_b.out 2>&1 || exit 1
 python3 $R/tools/pmc_tower.py $(find /tmp/pmc_b -name "*counter_collection.csv" | head -1) > $O/${tag}_tower_pmc_256_row.json
-tail -1 /tmp/pmc_a.out /tmp/pmc_b.out
+tail -n 1 /tmp/pmc_a.out; tail -n 1 /tmp/pmc_b.out
