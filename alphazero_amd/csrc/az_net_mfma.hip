@@ -786,6 +786,8 @@ struct MfmaNet {
     long long prof_rows = 0;
 };
 
+static int static_scratch(int device, unsigned char** out);   // defined beside az_net_forward_static below
+
 template <typename T>
 static int up(MfmaNet* m, const std::vector<T>& v, T** out) {
     void* p = nullptr;
@@ -1020,6 +1022,10 @@ int mfma_create(const az_net_config& c, const NetLayout& L, const float* Pm, Mfm
         m->max_grid = std::max(1, prop.multiProcessorCount);
         m->cus = m->max_grid;
         if (hipMalloc((void**)&m->xres, xres_bytes(m->max_grid, C, m->TB_duo > 0, m->rows_main)) != hipSuccess) { mfma_destroy(m); return fail(AZ_ERR_HIP, "hipMalloc (residual scratch)"); }
+        // The address of the library's static scratch array on this device is looked up here, at set-up, so that
+        // az_net_forward_static itself (possibly under graph capture) makes no symbol query. A failure is not an error
+        // of creation: the entry point repeats the lookup and reports it.
+        if (c.board_size <= 9) { unsigned char* unused = nullptr; (void)static_scratch(c.device, &unused); }
     } else {   // layer path: head activations (and value-tail shares) of one chunk, sized once
         int rcr = mfma_reserve(m, layers_chunk_boards(m->layers));
         if (rcr != AZ_OK) { mfma_destroy(m); return rcr; }
