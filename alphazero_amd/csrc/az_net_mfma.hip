@@ -760,6 +760,9 @@ struct MfmaNet {
     int TB, cin_pad, NH, q;
     std::vector<void*> allocs;
     TowerParams P;
+    // 64 channels: the 96-row variant is a 2x4-wave kernel reading weight fragments from global memory, while the main kernel
+    // (4x2 waves, weights through LDS) pairs its channel tiles differently: convolution images of its own
+    const uint4 *w_stem_small = nullptr, *w_tower_small = nullptr;
     float *w3, *b3, *wfcT, *bfc, *b4, *w6, *b6;
     uint16_t* w4T;
     uint16_t* w4p = nullptr;   // value fc1 packed for k_value_tail_mfma (null: hidden size too large, scalar tail)
@@ -857,7 +860,8 @@ int mfma_create(const az_net_config& c, const NetLayout& L, const float* Pm, Mfm
     if (m->rows_main == 384) m->split = 1;   // the 384-row kernel exists in the global-weights form only
     // the 96-row variant shares the 2x4-wave kernels' weight images: 128 / 192 channels in their default (global-weights)
     // form, boards of at most 96 points; AZ_TOWER_SMALL=0 switches it off
-    m->TB_small = (fused && m->split == 1 && (C == 128 || C == 192) && np <= 96) ? 96 / np : 0;
+    // 64 channels have it too (their main kernel is the LDS-staged one, so the variant gets weight images of its own)
+    m->TB_small = (fused && ((m->split == 1 && (C == 128 || C == 192)) || C == 64) && np <= 96) ? 96 / np : 0;
     if (const char* sm = getenv("AZ_TOWER_SMALL")) if (atoi(sm) == 0) m->TB_small = 0;
     // two 256-thread workgroups of two boards per compute unit (192 channels, global-weights form)
     // where whole boards fill at least 90 % of its 176 rows (duo_fill_ok); AZ_TOWER_DUO=0 switches it off
@@ -865,6 +869,7 @@ int mfma_create(const az_net_config& c, const NetLayout& L, const float* Pm, Mfm
     if (const char* du = getenv("AZ_TOWER_DUO")) if (atoi(du) == 0) m->TB_duo = 0;
     const int tiles_per_wave = C / 64;              // 2x4 waves: C/4 channels each
     const int slab_tiles = (m->split == 1 && (tiles_per_wave & 1)) ? tiles_per_wave : 0;   // channel tiles per wave when that count is odd
+    const bool small_images = m->TB_small > 0 && m->split == 0;   // (only C == 64) pack the 2x4-wave images beside the main ones
     if (fused && tower_lds_bytes(C, m->NH, m->TB, c.se_hidden, m->rows_main) > 160 * 1024) { delete m; return fail(AZ_ERR_ARG, "bf16 MFMA path: LDS budget exceeded"); }
     std::vector<float> w, b;
     TowerParams& P = m->P;
@@ -890,9 +895,13 @@ int mfma_create(const az_net_config& c, const NetLayout& L, const float* Pm, Mfm
         uint16_t* d; float* bd;
         TRY(up(m, pk, &d)); TRY(up(m, b, &bd));
         P.w_stem = (const uint4*)d; P.b_stem = bd;
+        if (small_images) {
+            pk = pack_conv(w, C, c.in_planes, 9, m->cin_pad, C, false, tiles_per_wave);
+            TRY(up(m, pk, &d)); m->w_stem_small = (const uint4*)d;
+        }
     }
     if (fused) {   // tower
-        std::vector<uint16_t> all;
+        std::vector<uint16_t> all, all_small;
         std::vector<float> ball;
         const size_t blob_bytes = se_blob_bytes(C, c.se_hidden);
         std::vector<uint8_t> blob(c.use_se ? blob_bytes * c.blocks : 0, 0);
@@ -901,9 +910,11 @@ int mfma_create(const az_net_config& c, const NetLayout& L, const float* Pm, Mfm
             fold_bn(Pm, bo.conv1, bo.bn1, C, (int64_t)C * 9, w, b);
             std::vector<uint16_t> pk = pack_conv(w, C, C, 9, C, C, false, slab_tiles);
             all.insert(all.end(), pk.begin(), pk.end()); ball.insert(ball.end(), b.begin(), b.end());
+            if (small_images) { pk = pack_conv(w, C, C, 9, C, C, false, tiles_per_wave); all_small.insert(all_small.end(), pk.begin(), pk.end()); }
             fold_bn(Pm, bo.conv2, bo.bn2, C, (int64_t)C * 9, w, b);
             pk = pack_conv(w, C, C, 9, C, C, false, slab_tiles);
             all.insert(all.end(), pk.begin(), pk.end()); ball.insert(ball.end(), b.begin(), b.end());
+            if (small_images) { pk = pack_conv(w, C, C, 9, C, C, false, tiles_per_wave); all_small.insert(all_small.end(), pk.begin(), pk.end()); }
             if (c.use_se) {
                 const int hid = c.se_hidden;
                 uint8_t* dst = blob.data() + blob_bytes * i;
@@ -922,6 +933,7 @@ int mfma_create(const az_net_config& c, const NetLayout& L, const float* Pm, Mfm
         }
         uint16_t* d; float* f; uint8_t* bl;
         TRY(up(m, all, &d)); P.w_tower = (const uint4*)d;
+        if (small_images) { TRY(up(m, all_small, &d)); m->w_tower_small = (const uint4*)d; }
         TRY(up(m, ball, &f)); P.b_tower = f;
         TRY(up(m, blob, &bl)); P.se_blob = (const uint4*)bl; P.se_vecs = (int)(blob_bytes / 16);
     }
@@ -989,6 +1001,9 @@ int mfma_create(const az_net_config& c, const NetLayout& L, const float* Pm, Mfm
         case 64:
             e = hipFuncSetAttribute((const void*)k_tower<64, 4, 2, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_tower<64, 2, 4, 32, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e == hipSuccess && m->TB_small)
+                e = hipFuncSetAttribute((const void*)k_tower<64, 2, 4, 32, 1, 96>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)tower_lds_bytes(C, m->NH, m->TB_small, c.se_hidden, 96));
             break;
         case 128:
             e = hipFuncSetAttribute((const void*)k_tower<128, 4, 2, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1229,10 +1244,12 @@ static int fused_forward(MfmaNet* m, const void* feat, int rows, const int* rows
     // Few positions: the 96-row variant gives every TB_small boards a workgroup of their own, so they spread over the
     // compute units instead of queueing three boards deep on a few. It wins while its workgroups fit two rounds
     // (a round takes about 0.4 of a 256-row round); `rows` is the upper bound when the count lives on the device.
-    const bool small = m->TB_small > 0 && (rows + m->TB_small - 1) / m->TB_small <= 2 * m->cus;
+    // 64 channels: one round only (measured at 9x9, 4 blocks: 64 against 83 us up to 256 boards, 104 against 87 us at 512).
+    const bool small = m->TB_small > 0 && (rows + m->TB_small - 1) / m->TB_small <= (C == 64 ? 1 : 2) * m->cus;
     const bool duo = !small && m->TB_duo > 0 && !static_scratch_call;
     const int TB = small ? m->TB_small : duo ? m->TB_duo : m->TB;
     P.TB = TB;
+    if (small && m->w_tower_small) { P.w_stem = m->w_stem_small; P.w_tower = m->w_tower_small; }
     P.items = (rows + TB - 1) / TB;
     P.rows_dev = rows_dev;
     const int grid = std::min(P.items, duo ? 2 * grid_cap : grid_cap);
@@ -1255,7 +1272,8 @@ static int fused_forward(MfmaNet* m, const void* feat, int rows, const int* rows
     switch (C) {
         case 32: hipLaunchKernelGGL((k_tower<32, 8, 1, 32>), dim3(grid), dim3(512), lds, st, P); break;
         case 64:
-            if (m->split == 1) hipLaunchKernelGGL((k_tower<64, 2, 4, 32, 1>), dim3(grid), dim3(512), lds, st, P);
+            if (small) hipLaunchKernelGGL((k_tower<64, 2, 4, 32, 1, 96>), dim3(grid), dim3(512), lds, st, P);
+            else if (m->split == 1) hipLaunchKernelGGL((k_tower<64, 2, 4, 32, 1>), dim3(grid), dim3(512), lds, st, P);
             else hipLaunchKernelGGL((k_tower<64, 4, 2, 32>), dim3(grid), dim3(512), lds, st, P);
             break;
         case 128:

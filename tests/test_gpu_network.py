@@ -114,6 +114,7 @@ def test_bf16_path_golden_weights(name):
 
 EXACT = [("fused", dict(board_size=9, channels=192, num_blocks=12), 40), ("fused", dict(board_size=9, channels=128, num_blocks=3), 40),
          ("fused", dict(board_size=9, channels=64, num_blocks=4, use_se=False), 41), ("fused", dict(board_size=5, channels=32, num_blocks=2, value_hidden_dim=64), 23),
+         ("fused", dict(board_size=5, channels=64, num_blocks=2, value_hidden_dim=64), 23),
          ("fused", dict(board_size=7, channels=128, num_blocks=3, history_len=4), 17), ("fused", dict(board_size=6, channels=192, num_blocks=2), 15),
          ("fused", dict(board_size=5, channels=192, num_blocks=2, value_hidden_dim=64), 30),
          ("fused", dict(board_size=13, channels=192, num_blocks=2), 7), ("fused", dict(board_size=13, channels=192, num_blocks=1, use_se=False, history_len=4), 2),
@@ -133,8 +134,8 @@ def test_bf16_exact_integer_network(path, kw, rows, small, monkeypatch):
     ragged last board group; the value (a tanh) to 2e-6."""
     import exactnet
     if small != "small_variant":
-        if path != "fused" or kw["channels"] < 128:
-            pytest.skip("only the fused 128/192-channel towers have a second (96-row, low-latency) kernel to switch off")
+        if path != "fused" or kw["channels"] < 64:
+            pytest.skip("only the fused 64/128/192-channel towers have a second (96-row, low-latency) kernel to switch off")
         monkeypatch.setenv("AZ_TOWER_SMALL", "0")       # few rows would otherwise all go through the 96-row variant
         if small == "256_row_kernel":
             monkeypatch.setenv("AZ_TOWER_DUO", "0")     # 192 channels on 9x9 / 5x5 otherwise run two 176-row workgroups per CU
@@ -174,7 +175,8 @@ def test_bf16_small_and_large_batches_agree_bitwise():
     from alphazero_amd.model import AlphaZeroNet
     import stubnets
     for kw in (dict(board_size=9, channels=192, num_blocks=3), dict(board_size=9, channels=128, num_blocks=2, use_se=False),
-               dict(board_size=6, channels=192, num_blocks=2)):
+               dict(board_size=6, channels=192, num_blocks=2), dict(board_size=9, channels=64, num_blocks=4),
+               dict(board_size=7, channels=64, num_blocks=2, use_se=False)):
         net = _default_init(kw, seed=8)
         n = kw["board_size"]
         x = stubnets.synthetic_planes(1400, 21, n, seed=4)
@@ -191,7 +193,7 @@ def test_bf16_small_and_large_batches_agree_bitwise():
             finally:
                 del os.environ["AZ_TOWER_DUO"]
             assert torch.equal(lg_256, lg_all) and torch.equal(v_256, v_all)
-        for lo, hi in ((0, 1), (5, 46), (700, 1100), (1390, 1400)):   # 1, 41, 400, 10 rows: 96-row kernel
+        for lo, hi in ((0, 1), (5, 46), (700, 1100), (900, 1100), (1390, 1400)):   # 1, 41, 400 (64 channels: main kernel), 200, 10 rows: 96-row kernel
             lg, v = nn(f[lo:hi].contiguous())
             assert torch.equal(lg, lg_all[lo:hi]) and torch.equal(v, v_all[lo:hi]), (kw, lo, hi)
 
