@@ -55,6 +55,8 @@ struct TowerParams {
     uint4* xres;                 // residual stream scratch: [gridDim.x][MI*NI*2][threads] 16-byte vectors, private per thread
     int items;                   // board groups (of TB boards) to process; workgroups stride over them
     const int* rows_dev;         // if set, the row count is read here (rows is then an upper bound)
+    int gate_mode, gate_rows;    // with rows_dev: 1 = this launch works only if the count is <= gate_rows, 2 = only if it is above
+                                 // (two launches, one per kernel variant; the one the count does not select leaves at once)
     unsigned long long* stamps;  // diagnostic build (-DAZ_STAMP) only: per-workgroup phase cycle sums
 };
 
@@ -377,6 +379,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void k_tower(TowerParams P) {
     TileGeo g;
     g.row0 = 0; g.n = P.n; g.np = P.np; g.recip_np = P.recip_np; g.recip_n = P.recip_n;
     const int rows = P.rows_dev ? min(*P.rows_dev, P.rows) : P.rows;
+    if ((P.gate_mode == 1 && rows > P.gate_rows) || (P.gate_mode == 2 && rows <= P.gate_rows)) return;   // the whole grid alike
     const int items = (rows + P.TB - 1) / P.TB;
     for (int item = blockIdx.x; item < items; item += gridDim.x) {
         const int board0 = item * P.TB;
@@ -1235,60 +1238,73 @@ static int fused_forward(MfmaNet* m, const void* feat, int rows, const int* rows
     const bool static_scratch_call = !timed;   // the static scratch array is laid out for the 256-row kernel
     const az_net_config& c = m->cfg;
     const int C = c.channels;
-    TowerParams P = m->P;
-    P.rows = rows;
-    P.feat = (const uint16_t*)feat;
-    P.hq = hq;
-    P.stamps = nullptr;
-    P.xres = xres;
+    TowerParams P;
     // Few positions: the 96-row variant gives every TB_small boards a workgroup of their own, so they spread over the
     // compute units instead of queueing three boards deep on a few. It wins while its workgroups fit two rounds
     // (a round takes about 0.4 of a 256-row round); `rows` is the upper bound when the count lives on the device.
-    // 64 channels: one round only (measured at 9x9, 4 blocks: 64 against 83 us up to 256 boards, 104 against 87 us at 512).
-    const bool small = m->TB_small > 0 && (rows + m->TB_small - 1) / m->TB_small <= (C == 64 ? 1 : 2) * m->cus;
-    const bool duo = !small && m->TB_duo > 0 && !static_scratch_call;
-    const int TB = small ? m->TB_small : duo ? m->TB_duo : m->TB;
-    P.TB = TB;
-    if (small && m->w_tower_small) { P.w_stem = m->w_stem_small; P.w_tower = m->w_tower_small; }
-    P.items = (rows + TB - 1) / TB;
-    P.rows_dev = rows_dev;
-    const int grid = std::min(P.items, duo ? 2 * grid_cap : grid_cap);
+    // 64 channels: one round only (measured at 9x9, 4 blocks: 64 against 83 us up to 256 boards, 104 against 87 us at 512);
+    // one round also where the alternative is the two-per-CU kernel (9x9 192ch x 12, lockstep moves of 512 games with about
+    // one row per game: 12.0 ms with that kernel against 14.9 ms with two rounds of the 96-row variant; 256 games: 11.0 / 8.6).
+    const int small_rounds = (C == 64 || m->TB_duo > 0) ? 1 : 2;
+    const int small_rows = m->TB_small > 0 ? small_rounds * m->cus * m->TB_small : 0;   // most rows the 96-row variant is chosen for
+    const bool small = rows <= small_rows;
+    // Count on the device and a bound above that limit (a search that evaluates a repeated leaf once has about one row per
+    // game under a bound of inference-batch rows per game): both variants are launched and the count picks the one that
+    // works; the other one's workgroups read the count and leave (a few microseconds). Not for bounds so large that
+    // few rows are implausible.
+    const bool both = !small && rows_dev != nullptr && small_rows > 0 && rows <= 16 * small_rows && !static_scratch_call;
 #ifdef AZ_STAMP
     static unsigned long long* stamp_dev = nullptr;
     static int stamp_grid = 0;
-    if (grid > stamp_grid) {
-        if (stamp_dev) (void)hipFree(stamp_dev);
-        (void)hipMalloc((void**)&stamp_dev, (size_t)grid * 8 * 128);
-        stamp_grid = grid;
-    }
-    P.stamps = stamp_dev;
 #endif
-    const size_t lds = tower_lds_bytes(C, m->NH, TB, c.se_hidden, small ? 96 : duo ? 176 : m->rows_main, duo);
     std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
     if (timed) {
         int rcp = prof_begin(m, rows_dev ? 0 : rows, st, &ev);   // indirect launches: the caller knows the row total
         if (rcp != AZ_OK) return rcp;
     }
-    switch (C) {
-        case 32: hipLaunchKernelGGL((k_tower<32, 8, 1, 32>), dim3(grid), dim3(512), lds, st, P); break;
-        case 64:
-            if (small) hipLaunchKernelGGL((k_tower<64, 2, 4, 32, 1, 96>), dim3(grid), dim3(512), lds, st, P);
-            else if (m->split == 1) hipLaunchKernelGGL((k_tower<64, 2, 4, 32, 1>), dim3(grid), dim3(512), lds, st, P);
-            else hipLaunchKernelGGL((k_tower<64, 4, 2, 32>), dim3(grid), dim3(512), lds, st, P);
-            break;
-        case 128:
-            if (small) hipLaunchKernelGGL((k_tower<128, 2, 4, 64, 1, 96>), dim3(grid), dim3(512), lds, st, P);
-            else if (m->rows_main == 384) hipLaunchKernelGGL((k_tower<128, 2, 4, 64, 1, 384>), dim3(grid), dim3(512), lds, st, P);
-            else if (m->split == 1) hipLaunchKernelGGL((k_tower<128, 2, 4, 64, 1>), dim3(grid), dim3(512), lds, st, P);
-            else hipLaunchKernelGGL((k_tower<128, 4, 2, 64>), dim3(grid), dim3(512), lds, st, P);
-            break;
-        case 192:
-            if (small) hipLaunchKernelGGL((k_tower<192, 2, 4, 96, 2, 96>), dim3(grid), dim3(512), lds, st, P);
-            else if (duo) hipLaunchKernelGGL((k_tower<192, 1, 4, 96, 2, 176, true, 2>), dim3(grid), dim3(256), lds, st, P);
-            else if (m->split == 1) hipLaunchKernelGGL((k_tower<192, 2, 4, 96, 2>), dim3(grid), dim3(512), lds, st, P);
-            else hipLaunchKernelGGL((k_tower<192, 4, 2, 96>), dim3(grid), dim3(512), lds, st, P);
-            break;
-        default: return fail(AZ_ERR_ARG, "unsupported channel count");
+    bool duo = false;
+    int grid = 0;
+    for (int pass = both ? 0 : 1; pass < 2; ++pass) {
+        const bool sm = both ? pass == 0 : small;
+        duo = !sm && m->TB_duo > 0 && !static_scratch_call;
+        const int TB = sm ? m->TB_small : duo ? m->TB_duo : m->TB;
+        P = m->P;
+        P.rows = rows; P.feat = (const uint16_t*)feat; P.hq = hq; P.stamps = nullptr; P.xres = xres; P.rows_dev = rows_dev;
+        P.TB = TB;
+        if (sm && m->w_tower_small) { P.w_stem = m->w_stem_small; P.w_tower = m->w_tower_small; }
+        P.items = (rows + TB - 1) / TB;
+        if (both) { P.gate_mode = sm ? 1 : 2; P.gate_rows = small_rows; }
+        grid = std::min(P.items, duo ? 2 * grid_cap : grid_cap);
+#ifdef AZ_STAMP
+        if (grid > stamp_grid) {
+            if (stamp_dev) (void)hipFree(stamp_dev);
+            (void)hipMalloc((void**)&stamp_dev, (size_t)grid * 8 * 128);
+            stamp_grid = grid;
+        }
+        P.stamps = stamp_dev;
+#endif
+        const size_t lds = tower_lds_bytes(C, m->NH, TB, c.se_hidden, sm ? 96 : duo ? 176 : m->rows_main, duo);
+        switch (C) {
+            case 32: hipLaunchKernelGGL((k_tower<32, 8, 1, 32>), dim3(grid), dim3(512), lds, st, P); break;
+            case 64:
+                if (sm) hipLaunchKernelGGL((k_tower<64, 2, 4, 32, 1, 96>), dim3(grid), dim3(512), lds, st, P);
+                else if (m->split == 1) hipLaunchKernelGGL((k_tower<64, 2, 4, 32, 1>), dim3(grid), dim3(512), lds, st, P);
+                else hipLaunchKernelGGL((k_tower<64, 4, 2, 32>), dim3(grid), dim3(512), lds, st, P);
+                break;
+            case 128:
+                if (sm) hipLaunchKernelGGL((k_tower<128, 2, 4, 64, 1, 96>), dim3(grid), dim3(512), lds, st, P);
+                else if (m->rows_main == 384) hipLaunchKernelGGL((k_tower<128, 2, 4, 64, 1, 384>), dim3(grid), dim3(512), lds, st, P);
+                else if (m->split == 1) hipLaunchKernelGGL((k_tower<128, 2, 4, 64, 1>), dim3(grid), dim3(512), lds, st, P);
+                else hipLaunchKernelGGL((k_tower<128, 4, 2, 64>), dim3(grid), dim3(512), lds, st, P);
+                break;
+            case 192:
+                if (sm) hipLaunchKernelGGL((k_tower<192, 2, 4, 96, 2, 96>), dim3(grid), dim3(512), lds, st, P);
+                else if (duo) hipLaunchKernelGGL((k_tower<192, 1, 4, 96, 2, 176, true, 2>), dim3(grid), dim3(256), lds, st, P);
+                else if (m->split == 1) hipLaunchKernelGGL((k_tower<192, 2, 4, 96, 2>), dim3(grid), dim3(512), lds, st, P);
+                else hipLaunchKernelGGL((k_tower<192, 4, 2, 96>), dim3(grid), dim3(512), lds, st, P);
+                break;
+            default: return fail(AZ_ERR_ARG, "unsupported channel count");
+        }
     }
     if (ev) (void)hipEventRecord(ev->second, st);
     run_tails(m, hq, rows, rows_dev, 0, logits, values, st);

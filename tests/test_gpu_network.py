@@ -193,7 +193,7 @@ def test_bf16_small_and_large_batches_agree_bitwise():
             finally:
                 del os.environ["AZ_TOWER_DUO"]
             assert torch.equal(lg_256, lg_all) and torch.equal(v_256, v_all)
-        for lo, hi in ((0, 1), (5, 46), (700, 1100), (900, 1100), (1390, 1400)):   # 1, 41, 400 (64 channels: main kernel), 200, 10 rows: 96-row kernel
+        for lo, hi in ((0, 1), (5, 46), (700, 1100), (900, 1100), (1390, 1400)):   # 1, 41, 400 (64 and 192 channels on 9x9: main kernel), 200, 10 rows: 96-row kernel
             lg, v = nn(f[lo:hi].contiguous())
             assert torch.equal(lg, lg_all[lo:hi]) and torch.equal(v, v_all[lo:hi]), (kw, lo, hi)
 
@@ -365,6 +365,32 @@ def test_layer_path_forward_indirect_equals_direct(channels):
         k = min(live, 23)
         assert torch.equal(lb[:k], lg[:k]) and torch.equal(vb[:k], v[:k])
         assert bool((lb[live:] == -7.0).all()) and bool((vb[live:] == -7.0).all())
+
+
+@pytest.mark.parametrize("kw,limit", [(dict(board_size=9, channels=64, num_blocks=2), 256), (dict(board_size=9, channels=192, num_blocks=2), 256),
+                                      (dict(board_size=5, channels=128, num_blocks=1, use_se=False), 1536)],
+                         ids=lambda v: f"n{v['board_size']}_c{v['channels']}" if isinstance(v, dict) else str(v))
+def test_fused_forward_indirect_picks_the_kernel_on_the_device(kw, limit):
+    """az_net_forward_indirect under a row bound above the 96-row variant's limit launches both that variant and the main
+    kernel; the count in device memory decides which one works. Counts on either side of the limit give az_net_forward's
+    bits for the live rows and leave the rest of the output untouched."""
+    import stubnets
+    net = _default_init(kw, seed=5)
+    n, A = kw["board_size"], kw["board_size"] ** 2 + 1
+    bound = limit + 400
+    dev = torch.device("cuda:0")
+    nn = net.to(dev).native("bf16", shared=False)
+    assert nn.fused and nn.indirect
+    f = _to_nhwc_bf16(stubnets.synthetic_planes(bound, 21, n, seed=2)).to(dev)
+    nn.reserve(bound)
+    lg, v = nn(f)                                              # direct, `bound` rows: the main kernel
+    for live in (1, limit, limit + 1, bound, 37):
+        rows_dev = torch.tensor([live], dtype=torch.int32, device=dev)
+        lb = torch.full((bound, A), -7.0, dtype=torch.float32, device=dev)
+        vb = torch.full((bound,), -7.0, dtype=torch.float32, device=dev)
+        nn.forward_indirect(f, rows_dev.data_ptr(), bound, lb, vb)
+        assert torch.equal(lb[:live], lg[:live]) and torch.equal(vb[:live], v[:live]), live
+        assert bool((lb[live:] == -7.0).all()) and bool((vb[live:] == -7.0).all()), live
 
 
 def test_reserve_then_forward():
