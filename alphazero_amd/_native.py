@@ -75,6 +75,7 @@ SIGNATURES = {
     "az_net_forward_indirect": (_I32, [_VP, _VP, _VP, _I32, _VP, _VP, _VP]),
     "az_net_profile_spans": (_I32, [_VP, _VP, C.c_int64, C.POINTER(C.c_int64)]),
     "az_net_set_tower_workgroups": (_I32, [_VP, _I32]),
+    "az_net_set_device_choice": (_I32, [_VP, _I32]),
     "az_net_profile": (_I32, [_VP, _I32, C.POINTER(C.c_double), C.POINTER(_I64), C.POINTER(_I64)]),
     "az_replay_gather": (_I32, [_VP, _VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _VP, _VP, _VP]),
     "az_pack_planes": (_I32, [_VP, _I32, _I32, _I32, _I32, _VP, _VP, _VP]),

@@ -44,6 +44,7 @@ void mfma_set_profiling(MfmaNet* m, bool on);
 int mfma_profile(MfmaNet* m, double* tower_ms, long long* launches, long long* rows);
 int mfma_profile_spans(MfmaNet* m, double* spans, long long cap, long long* count);
 int mfma_set_grid_limit(MfmaNet* m, int workgroups);
+void mfma_set_device_choice(MfmaNet* m, bool on);
 int mfma_forward(MfmaNet* m, const void* feat_bf16_nhwc, int rows, const int* rows_dev, float* logits, float* values, hipStream_t st);
 int mfma_reserve(MfmaNet* m, int rows);
 int mfma_forward_static(MfmaNet* m, const void* feat_bf16_nhwc, int rows, float* logits, float* values, hipStream_t st);

@@ -296,6 +296,13 @@ int az_net_set_tower_workgroups(az_net* net, int32_t workgroups) {
     return mfma_set_grid_limit(net->mfma, workgroups);
 }
 
+int az_net_set_device_choice(az_net* net, int32_t on) {
+    if (!net) return fail(AZ_ERR_ARG, "null network");
+    if (net->cfg.precision != AZ_NET_BF16 || !net->mfma) return fail(AZ_ERR_STATE, "az_net_set_device_choice: bf16 network not loaded");
+    mfma_set_device_choice(net->mfma, on != 0);
+    return AZ_OK;
+}
+
 int az_net_profile(az_net* net, int32_t enable, double* tower_ms, int64_t* launches, int64_t* rows) {
     if (!net) return fail(AZ_ERR_ARG, "null network");
     if (net->cfg.precision != AZ_NET_BF16 || !net->mfma) return fail(AZ_ERR_STATE, "az_net_profile: bf16 network not loaded");

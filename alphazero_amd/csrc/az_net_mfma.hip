@@ -782,6 +782,7 @@ struct MfmaNet {
                                   // them, so they are only freed with the network (sizes grow geometrically: bounded waste)
     int TB_duo = 0;               // boards per workgroup of the two-workgroups-per-CU variant (176 rows, 256 threads; 0: none)
     int TB_small = 0;             // boards per workgroup of the 96-row low-latency variant (0: this shape has none)
+    bool device_choice = true;    // indirect forwards under a moderate bound launch the 96-row variant too, gated on the count
     int rows_main = 256;          // rows of the main kernel's workgroup: 256, or 384 for one board of 17x17 to 19x19 (128 channels)
     int split = 0;                // 0: 4x2 waves, weights through LDS; 1: 2x4 waves, weight fragments from global memory (C = 192)
     LayerNet* layers = nullptr;   // set instead of the fused tower's weights when the shape needs the layer-by-layer path
@@ -1097,6 +1098,8 @@ static int base_event(int device, hipEvent_t* out) {
     return AZ_OK;
 }
 
+void mfma_set_device_choice(MfmaNet* m, bool on) { m->device_choice = on; }
+
 int mfma_set_grid_limit(MfmaNet* m, int workgroups) {
     if (workgroups < 1) return fail(AZ_ERR_ARG, "workgroup limit must be >= 1");
     if (m->layers) return AZ_OK;   // the layer path has no resident workgroups
@@ -1251,8 +1254,8 @@ static int fused_forward(MfmaNet* m, const void* feat, int rows, const int* rows
     // Count on the device and a bound above that limit (a search that evaluates a repeated leaf once has about one row per
     // game under a bound of inference-batch rows per game): both variants are launched and the count picks the one that
     // works; the other one's workgroups read the count and leave (a few microseconds). Not for bounds so large that
-    // few rows are implausible.
-    const bool both = !small && rows_dev != nullptr && small_rows > 0 && rows <= 16 * small_rows && !static_scratch_call;
+    // few rows are implausible (32 times the limit: inference batches of up to 32 rows per game).
+    const bool both = !small && m->device_choice && rows_dev != nullptr && small_rows > 0 && rows <= 32 * (long long)small_rows && !static_scratch_call;
 #ifdef AZ_STAMP
     static unsigned long long* stamp_dev = nullptr;
     static int stamp_grid = 0;

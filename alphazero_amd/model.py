@@ -220,6 +220,11 @@ class NativeNet:
                                                C.c_void_p(logits.data_ptr()), C.c_void_p(values.data_ptr()), st),
                 "az_net_forward_indirect")
 
+    def set_device_choice(self, on: bool):
+        """Whether forward_indirect may launch the low-latency tower variant beside the main kernel and let the row count
+        on the device pick one (default on; drivers with three or more concurrent streams switch it off)."""
+        N.check(self.L.az_net_set_device_choice(self._h, 1 if on else 0), "az_net_set_device_choice")
+
     def set_tower_workgroups(self, workgroups: int):
         N.check(self.L.az_net_set_tower_workgroups(self._h, int(workgroups)), "az_net_set_tower_workgroups")
 

@@ -419,6 +419,16 @@ class BatchedSelfPlay:
         share = [self.G // lanes + (1 if i < self.G % lanes else 0) for i in range(lanes)]
         self.lanes = [_Lane(self, i, g, model, precision, dedup_leaves, rng_threads, own_stream=lanes > 1)
                       for i, g in enumerate(share)]
+        # The low-latency tower variant takes the whole device per launch (one workgroup per compute unit): right for one
+        # lane (256 games: 8.7 ms per move against 11.0), wrong for three or more sharing the card (768 games in 3 lanes:
+        # 19.2 ms against 15.7). Two lanes: only where a lane's rows (about one per game) can be within that variant's limit
+        # of one board per compute unit; otherwise the variant's gated-off launch would still queue behind the other lane's
+        # workgroups for a compute unit of its own before it can leave (1024 games in 2 lanes: +4 % per move).
+        cus = torch.cuda.get_device_properties(self.dev).multi_processor_count
+        if lanes > 2 or (lanes == 2 and max(share) > cus):
+            for ln in self.lanes:
+                if ln.net is not None and ln.net.precision == "bf16":
+                    ln.net.set_device_choice(False)
         if tower_workgroups is not None:
             for ln in self.lanes:
                 if ln.net is not None and ln.net.precision == "bf16":

@@ -419,7 +419,11 @@ def run_selfplay(best_model, cfg, iter_idx: int, pool=None, model_path=None, mod
     best_model.eval()
     on_gpu = next(best_model.parameters()).is_cuda
     slots = min(mine, cfg.lockstep_games if cfg.lockstep_games > 0 else 4096)
-    lanes = cfg.selfplay_lanes if cfg.selfplay_lanes > 0 else (4 if slots >= 2048 else 3 if slots >= 768 else 2 if slots >= 512 else 1)
+    # measured on the 192ch x 12 network (ms per lockstep move, lanes 1/2/3/4): 512 games 12.1/13.5/-/-, 768 games 17.7/15.0/15.7/-,
+    # 1024 games 20.3/17.6/18.9/18.7, 2048 games -/33.8/-/33.5, 4096 games: 4 lanes; a light network (64ch x 4) is bound by the
+    # host half of a move, which a second lane hides from 512 games on
+    light = cfg.channels * cfg.num_blocks <= 512
+    lanes = cfg.selfplay_lanes if cfg.selfplay_lanes > 0 else (4 if slots >= 2048 else 2 if slots >= 768 or (light and slots >= 512) else 1)
     sp = BatchedSelfPlay(best_model if on_gpu else _host_evaluator(best_model), SelfPlayConfig.from_train_config(cfg), games=slots,
                          seed0=selfplay_seed0(cfg, iter_idx) + first, dedup_leaves=not cfg.no_dedup_leaves, lanes=lanes,
                          tower_workgroups=1024 if lanes > 1 else None)

@@ -225,6 +225,13 @@ int az_net_profile_spans(az_net* net, double* spans_ms, int64_t capacity, int64_
  * each looping over its share of the boards). A larger limit gives shorter-lived workgroups, which lets
  * launches on other streams interleave at board-group granularity. Synchronises the device. */
 int az_net_set_tower_workgroups(az_net* net, int32_t workgroups);
+/* az_net_forward_indirect under a row bound of up to 32 times the low-latency tower variant's limit launches that
+ * variant and the main kernel, and the count in device memory picks the one that works (on != 0, the default).
+ * The low-latency variant holds every compute unit with one workgroup, which is what a single stream of searches
+ * wants and what three or more streams sharing the device do not: their driver switches the choice off (on == 0)
+ * and the main kernel runs whatever the count. Results are the same bits either way. bf16 path only; no upstream
+ * counterpart (host-side switch of the GPU engine). */
+int az_net_set_device_choice(az_net* net, int32_t on);
 
 /* ---- host-side random streams (no device work) ------------------------------------------------ */
 /* One legacy-NumPy-compatible MT19937 stream per game. The upstream code draws from the global

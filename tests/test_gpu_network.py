@@ -391,6 +391,13 @@ def test_fused_forward_indirect_picks_the_kernel_on_the_device(kw, limit):
         nn.forward_indirect(f, rows_dev.data_ptr(), bound, lb, vb)
         assert torch.equal(lb[:live], lg[:live]) and torch.equal(vb[:live], v[:live]), live
         assert bool((lb[live:] == -7.0).all()) and bool((vb[live:] == -7.0).all()), live
+    nn.set_device_choice(False)                                # the main kernel whatever the count: same bits
+    for live in (1, limit + 1):
+        rows_dev = torch.tensor([live], dtype=torch.int32, device=dev)
+        lb = torch.full((bound, A), -7.0, dtype=torch.float32, device=dev)
+        vb = torch.full((bound,), -7.0, dtype=torch.float32, device=dev)
+        nn.forward_indirect(f, rows_dev.data_ptr(), bound, lb, vb)
+        assert torch.equal(lb[:live], lg[:live]) and torch.equal(vb[:live], v[:live]) and bool((lb[live:] == -7.0).all())
 
 
 def test_reserve_then_forward():
