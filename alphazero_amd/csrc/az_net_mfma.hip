@@ -352,6 +352,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void k_tower(TowerParams P) {
     constexpr int MI = ROWS / (WM * 16), NI = C / (WN * 16);
     constexpr int MIH = (ROWS + NW * 16 - 1) / (NW * 16), NIH = NH / 16;   // head: the waves split the row tiles; waves past ROWS compute zeros
     constexpr int STRIDE = 2 * C + 32;
+    constexpr int RING = MI > AZ_RING ? AZ_RING : 4;   // activation-fragment ring of gemm_conv_ring: fewer than the row tiles a wave owns
     constexpr int NV = MI * (NI / 2) + ((NI & 1) ? (MI + 1) / 2 : 0);  // 16-byte vectors of packed bf16 residual per thread
     static_assert(ROWS % (WM * 16) == 0 && NIH % 2 == 0, "whole row tiles per wave; head channel tiles are stored in pairs");
     static_assert(NW * 16 * MIH * (2 * NH + 16) <= ROWS * STRIDE, "the head activations of every wave's row tiles must fit the activation image");
@@ -420,7 +421,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void k_tower(TowerParams P) {
         const size_t conv_vecs = (size_t)NKS * 32 * C * 2 / 16;
         for (int blk = 0; blk < P.blocks; ++blk) {
             zero_acc<MI, NI>(acc);
-            if constexpr (LEAN && WM == 1) gemm_conv_ring<MI, NI, WN, C, KPT, GW, AZ_RING>(acc, P.w_tower + (size_t)(2 * blk) * conv_vecs, 9, act, taptab);
+            if constexpr (LEAN && WM == 1) gemm_conv_ring<MI, NI, WN, C, KPT, GW, RING>(acc, P.w_tower + (size_t)(2 * blk) * conv_vecs, 9, act, taptab);
             else if constexpr (SAME && GW > 0) gemm_conv_gw<MI, NI, WM, WN, C, KPT, GW>(acc, P.w_tower + (size_t)(2 * blk) * conv_vecs, 9, true, act, STRIDE, zrow, g);
             else if constexpr (SAME) gemm_conv<MI, NI, WM, WN, C, KPT>(acc, P.w_tower + (size_t)(2 * blk) * conv_vecs, 9, true, act, STRIDE, zrow, bbuf, g);
             else gemm_taps<MI, NI, WM, WN, C, false>(acc, P.w_tower + (size_t)(2 * blk) * conv_vecs, NKS, KPT, 9, true, act, STRIDE, zrow, bbuf, g);
@@ -428,7 +429,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void k_tower(TowerParams P) {
             store_act<MI, NI, WM, WN, STRIDE, true, false>(acc, P.b_tower + (size_t)(2 * blk) * C, act, xres_wg);
             STAMP(3);
             zero_acc<MI, NI>(acc);
-            if constexpr (LEAN && WM == 1) gemm_conv_ring<MI, NI, WN, C, KPT, GW, AZ_RING>(acc, P.w_tower + (size_t)(2 * blk + 1) * conv_vecs, 9, act, taptab);
+            if constexpr (LEAN && WM == 1) gemm_conv_ring<MI, NI, WN, C, KPT, GW, RING>(acc, P.w_tower + (size_t)(2 * blk + 1) * conv_vecs, 9, act, taptab);
             else if constexpr (SAME && GW > 0) gemm_conv_gw<MI, NI, WM, WN, C, KPT, GW>(acc, P.w_tower + (size_t)(2 * blk + 1) * conv_vecs, 9, true, act, STRIDE, zrow, g);
             else if constexpr (SAME) gemm_conv<MI, NI, WM, WN, C, KPT>(acc, P.w_tower + (size_t)(2 * blk + 1) * conv_vecs, 9, true, act, STRIDE, zrow, bbuf, g);
             else gemm_taps<MI, NI, WM, WN, C, false>(acc, P.w_tower + (size_t)(2 * blk + 1) * conv_vecs, NKS, KPT, 9, true, act, STRIDE, zrow, bbuf, g);
@@ -781,6 +782,7 @@ struct MfmaNet {
     std::vector<void*> retired;   // scratch buffers that were replaced by larger ones: launches already enqueued may still use
                                   // them, so they are only freed with the network (sizes grow geometrically: bounded waste)
     int TB_duo = 0;               // boards per workgroup of the two-workgroups-per-CU variant (176 rows, 256 threads; 0: none)
+    bool small_lean = false;      // the 96-row variant as 256-thread workgroups, two per compute unit (192 channels)
     int TB_small = 0;             // boards per workgroup of the 96-row low-latency variant (0: this shape has none)
     bool device_choice = true;    // indirect forwards under a moderate bound launch the 96-row variant too, gated on the count
     int rows_main = 256;          // rows of the main kernel's workgroup: 256, or 384 for one board of 17x17 to 19x19 (128 channels)
@@ -871,6 +873,8 @@ int mfma_create(const az_net_config& c, const NetLayout& L, const float* Pm, Mfm
     // where whole boards fill at least 90 % of its 176 rows (duo_fill_ok); AZ_TOWER_DUO=0 switches it off
     m->TB_duo = (fused && m->split == 1 && C == 192 && duo_fill_ok(np)) ? 176 / np : 0;
     if (const char* du = getenv("AZ_TOWER_DUO")) if (atoi(du) == 0) m->TB_duo = 0;
+    m->small_lean = m->TB_small > 0 && m->TB_duo > 0 && np <= 96;
+    if (const char* sl = getenv("AZ_TOWER_SMALL_LEAN")) if (atoi(sl) == 0) m->small_lean = false;
     const int tiles_per_wave = C / 64;              // 2x4 waves: C/4 channels each
     const int slab_tiles = (m->split == 1 && (tiles_per_wave & 1)) ? tiles_per_wave : 0;   // channel tiles per wave when that count is odd
     const bool small_images = m->TB_small > 0 && m->split == 0;   // (only C == 64) pack the 2x4-wave images beside the main ones
@@ -1027,6 +1031,9 @@ int mfma_create(const az_net_config& c, const NetLayout& L, const float* Pm, Mfm
             if (e == hipSuccess && m->TB_duo)
                 e = hipFuncSetAttribute((const void*)k_tower<192, 1, 4, 96, 2, 176, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)tower_lds_bytes(C, m->NH, m->TB_duo, c.se_hidden, 176, true));
+            if (e == hipSuccess && m->small_lean)
+                e = hipFuncSetAttribute((const void*)k_tower<192, 1, 4, 96, 2, 96, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)tower_lds_bytes(C, m->NH, m->TB_small, c.se_hidden, 96, true));
             break;
     }
     if (e != hipSuccess) { mfma_destroy(m); return fail(AZ_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e)); }
@@ -1248,6 +1255,10 @@ static int fused_forward(MfmaNet* m, const void* feat, int rows, const int* rows
     // 64 channels: one round only (measured at 9x9, 4 blocks: 64 against 83 us up to 256 boards, 104 against 87 us at 512);
     // one round also where the alternative is the two-per-CU kernel (9x9 192ch x 12, lockstep moves of 512 games with about
     // one row per game: 12.0 ms with that kernel against 14.9 ms with two rounds of the 96-row variant; 256 games: 11.0 / 8.6).
+    // 192 channels: the variant runs as 256-thread workgroups that read every weight fragment once per compute unit (9x9 x 12
+    // blocks, forward of 256 boards: 0.418 ms against 0.450 ms with 512 threads; no difference at 64 boards; two of them per
+    // compute unit for 257 to 512 boards are no faster than the two-per-CU main kernel: 0.709 against 0.675 ms at 512)
+    const bool lean_small = m->small_lean && !static_scratch_call;
     const int small_rounds = (C == 64 || m->TB_duo > 0) ? 1 : 2;
     const int small_rows = m->TB_small > 0 ? small_rounds * m->cus * m->TB_small : 0;   // most rows the 96-row variant is chosen for
     const bool small = rows <= small_rows;
@@ -1277,7 +1288,8 @@ static int fused_forward(MfmaNet* m, const void* feat, int rows, const int* rows
         if (sm && m->w_tower_small) { P.w_stem = m->w_stem_small; P.w_tower = m->w_tower_small; }
         P.items = (rows + TB - 1) / TB;
         if (both) { P.gate_mode = sm ? 1 : 2; P.gate_rows = small_rows; }
-        grid = std::min(P.items, duo ? 2 * grid_cap : grid_cap);
+        const bool lean = duo || (sm && lean_small);
+        grid = std::min(P.items, lean ? 2 * grid_cap : grid_cap);
 #ifdef AZ_STAMP
         if (grid > stamp_grid) {
             if (stamp_dev) (void)hipFree(stamp_dev);
@@ -1286,7 +1298,7 @@ static int fused_forward(MfmaNet* m, const void* feat, int rows, const int* rows
         }
         P.stamps = stamp_dev;
 #endif
-        const size_t lds = tower_lds_bytes(C, m->NH, TB, c.se_hidden, sm ? 96 : duo ? 176 : m->rows_main, duo);
+        const size_t lds = tower_lds_bytes(C, m->NH, TB, c.se_hidden, sm ? 96 : duo ? 176 : m->rows_main, lean);
         switch (C) {
             case 32: hipLaunchKernelGGL((k_tower<32, 8, 1, 32>), dim3(grid), dim3(512), lds, st, P); break;
             case 64:
@@ -1301,7 +1313,8 @@ static int fused_forward(MfmaNet* m, const void* feat, int rows, const int* rows
                 else hipLaunchKernelGGL((k_tower<128, 4, 2, 64>), dim3(grid), dim3(512), lds, st, P);
                 break;
             case 192:
-                if (sm) hipLaunchKernelGGL((k_tower<192, 2, 4, 96, 2, 96>), dim3(grid), dim3(512), lds, st, P);
+                if (sm && lean_small) hipLaunchKernelGGL((k_tower<192, 1, 4, 96, 2, 96, true, 2>), dim3(grid), dim3(256), lds, st, P);
+                else if (sm) hipLaunchKernelGGL((k_tower<192, 2, 4, 96, 2, 96>), dim3(grid), dim3(512), lds, st, P);
                 else if (duo) hipLaunchKernelGGL((k_tower<192, 1, 4, 96, 2, 176, true, 2>), dim3(grid), dim3(256), lds, st, P);
                 else if (m->split == 1) hipLaunchKernelGGL((k_tower<192, 2, 4, 96, 2>), dim3(grid), dim3(512), lds, st, P);
                 else hipLaunchKernelGGL((k_tower<192, 4, 2, 96>), dim3(grid), dim3(512), lds, st, P);

@@ -193,6 +193,13 @@ def test_bf16_small_and_large_batches_agree_bitwise():
             finally:
                 del os.environ["AZ_TOWER_DUO"]
             assert torch.equal(lg_256, lg_all) and torch.equal(v_256, v_all)
+            os.environ["AZ_TOWER_SMALL_LEAN"] = "0"
+            try:
+                nn512 = net.native("bf16", shared=False)        # the 96-row variant as 512-thread workgroups (the default
+                lg_s, v_s = nn512(f[100:300].contiguous())      # for 192 channels is the 256-thread form)
+            finally:
+                del os.environ["AZ_TOWER_SMALL_LEAN"]
+            assert torch.equal(lg_s, lg_all[100:300]) and torch.equal(v_s, v_all[100:300])
         for lo, hi in ((0, 1), (5, 46), (700, 1100), (900, 1100), (1390, 1400)):   # 1, 41, 400 (64 and 192 channels on 9x9: main kernel), 200, 10 rows: 96-row kernel
             lg, v = nn(f[lo:hi].contiguous())
             assert torch.equal(lg, lg_all[lo:hi]) and torch.equal(v, v_all[lo:hi]), (kw, lo, hi)
