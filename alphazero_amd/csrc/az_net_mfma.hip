@@ -352,6 +352,10 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void k_tower(TowerParams P) {
     constexpr int MI = ROWS / (WM * 16), NI = C / (WN * 16);
     constexpr int MIH = (ROWS + NW * 16 - 1) / (NW * 16), NIH = NH / 16;   // head: the waves split the row tiles; waves past ROWS compute zeros
     constexpr int STRIDE = 2 * C + 32;
+    // The 96-row LEAN form has LDS to spare and mostly runs alone on its compute unit (few positions): its squeeze-excite
+    // weights are staged in LDS like the 512-thread kernels' (reading them from global memory, which the 176-row form hides
+    // behind the compute unit's other workgroup, cost 9 % of a lone workgroup's cycles in fc2 alone).
+    constexpr bool SE_LDS = LEAN && ROWS == 96;
     constexpr int RING = MI > AZ_RING ? AZ_RING : 4;   // activation-fragment ring of gemm_conv_ring: fewer than the row tiles a wave owns
     constexpr int NV = MI * (NI / 2) + ((NI & 1) ? (MI + 1) / 2 : 0);  // 16-byte vectors of packed bf16 residual per thread
     static_assert(ROWS % (WM * 16) == 0 && NIH % 2 == 0, "whole row tiles per wave; head channel tiles are stored in pairs");
@@ -363,7 +367,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void k_tower(TowerParams P) {
     char* bbuf = zrow + ZBYTES;
     float* scratch = (float*)bbuf;  // epilogue scratch shares the weight staging buffers
     // LEAN: the tap table of gemm_conv_ring follows the squeeze-excite scratch (tower_lds_bytes)
-    uint16_t* taptab = (uint16_t*)(bbuf + ((((size_t)2 * P.TB * C + (size_t)P.TB * P.hid) * 4 + 16 + 15) & ~(size_t)15));
+    uint16_t* taptab = (uint16_t*)(bbuf + ((((size_t)2 * P.TB * C + (size_t)P.TB * P.hid) * 4 + 16 + 15) & ~(size_t)15) + (SE_LDS ? (size_t)P.se_vecs * 16 : 0));
     (void)taptab;
     const int tid = threadIdx.x;
     uint4* xres_wg = P.xres + (size_t)blockIdx.x * NV * NT;
@@ -462,9 +466,9 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void k_tower(TowerParams P) {
                 store_act<MI, NI, WM, WN, STRIDE, false, false>(acc, nullptr, act, xres_wg);   // bf16 image of y for the pooling
                 STAMP(7);
 #ifdef AZ_STAMP
-                se_gate<MI, NI, WM, WN, C, STRIDE, LEAN>(acc, act, scratch, P.se_blob + (size_t)blk * P.se_vecs, P.se_vecs, P.hid, P.TB, nb, g, stamp_acc, stamp_last);
+                se_gate<MI, NI, WM, WN, C, STRIDE, LEAN && !SE_LDS>(acc, act, scratch, P.se_blob + (size_t)blk * P.se_vecs, P.se_vecs, P.hid, P.TB, nb, g, stamp_acc, stamp_last);
 #else
-                se_gate<MI, NI, WM, WN, C, STRIDE, LEAN>(acc, act, scratch, P.se_blob + (size_t)blk * P.se_vecs, P.se_vecs, P.hid, P.TB, nb, g);
+                se_gate<MI, NI, WM, WN, C, STRIDE, LEAN && !SE_LDS>(acc, act, scratch, P.se_blob + (size_t)blk * P.se_vecs, P.se_vecs, P.hid, P.TB, nb, g);
 #endif
             }
             STAMP(4);
@@ -844,6 +848,7 @@ static size_t tower_lds_bytes(int C, int NH, int TB, int hid, int rows = 256, bo
     const size_t stride = 2 * C + 32;
     const size_t tile = lean ? 0 : (size_t)64 * std::max(C, NH) * 2;
     const size_t se = lean ? ((((size_t)2 * TB * C + (size_t)TB * hid) * 4 + 16 + 15) & ~(size_t)15) + (size_t)9 * rows * 2   // + tap table
+                                 + (rows == 96 ? se_blob_bytes(C, hid) : 0)   // the 96-row form stages the squeeze-excite weights
                            : ((size_t)2 * TB * C + (size_t)TB * hid) * 4 + 16 + se_blob_bytes(C, hid);
     const size_t zbytes = ((256 + 2 * (size_t)C + 16 + 127) / 128) * 128;
     return (((size_t)rows * stride + 255) / 256) * 256 + zbytes + std::max(2 * tile, se);
@@ -1328,7 +1333,7 @@ static int fused_forward(MfmaNet* m, const void* feat, int rows, const int* rows
     if (err != hipSuccess) return fail(AZ_ERR_HIP, std::string("bf16 forward: ") + hipGetErrorString(err));
 #ifdef AZ_STAMP
     {   // diagnostic build: print where a workgroup's cycles go (mean over workgroups)
-        const int nwv = duo ? 4 : 8;   // waves per workgroup
+        const int nwv = (duo || (small && lean_small)) ? 4 : 8;   // waves per workgroup
         std::vector<unsigned long long> hst((size_t)grid * nwv * 16);
         (void)hipDeviceSynchronize();
         (void)hipMemcpy(hst.data(), P.stamps, hst.size() * 8, hipMemcpyDeviceToHost);
