@@ -1037,7 +1037,7 @@ int mfma_create(const az_net_config& c, const NetLayout& L, const float* Pm, Mfm
                 e = hipFuncSetAttribute((const void*)k_tower<192, 1, 4, 96, 2, 176, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)tower_lds_bytes(C, m->NH, m->TB_duo, c.se_hidden, 176, true));
             if (e == hipSuccess && m->small_lean)
-                e = hipFuncSetAttribute((const void*)k_tower<192, 1, 4, 96, 2, 96, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                e = hipFuncSetAttribute((const void*)k_tower<192, 1, 4, 96, 5, 96, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)tower_lds_bytes(C, m->NH, m->TB_small, c.se_hidden, 96, true));
             break;
     }
@@ -1262,7 +1262,9 @@ static int fused_forward(MfmaNet* m, const void* feat, int rows, const int* rows
     // one row per game: 12.0 ms with that kernel against 14.9 ms with two rounds of the 96-row variant; 256 games: 11.0 / 8.6).
     // 192 channels: the variant runs as 256-thread workgroups that read every weight fragment once per compute unit (9x9 x 12
     // blocks, forward of 256 boards: 0.418 ms against 0.450 ms with 512 threads; no difference at 64 boards; two of them per
-    // compute unit for 257 to 512 boards are no faster than the two-per-CU main kernel: 0.709 against 0.675 ms at 512)
+    // compute unit for 257 to 512 boards are no faster than the two-per-CU main kernel: 0.709 against 0.675 ms at 512).
+    // It keeps 5 k-steps of weight fragments in flight instead of 2 (a lone wave per SIMD has no other wave to cover the
+    // L2 latency: forward of 1 / 40 / 96 / 160 / 256 boards 0.347 / 0.350 / 0.353 / 0.364 / 0.41 -> 0.320 / 0.330 / 0.342 / 0.360 / 0.41 ms).
     const bool lean_small = m->small_lean && !static_scratch_call;
     const int small_rounds = (C == 64 || m->TB_duo > 0) ? 1 : 2;
     const int small_rows = m->TB_small > 0 ? small_rounds * m->cus * m->TB_small : 0;   // most rows the 96-row variant is chosen for
@@ -1318,7 +1320,7 @@ static int fused_forward(MfmaNet* m, const void* feat, int rows, const int* rows
                 else hipLaunchKernelGGL((k_tower<128, 4, 2, 64>), dim3(grid), dim3(512), lds, st, P);
                 break;
             case 192:
-                if (sm && lean_small) hipLaunchKernelGGL((k_tower<192, 1, 4, 96, 2, 96, true, 2>), dim3(grid), dim3(256), lds, st, P);
+                if (sm && lean_small) hipLaunchKernelGGL((k_tower<192, 1, 4, 96, 5, 96, true, 2>), dim3(grid), dim3(256), lds, st, P);
                 else if (sm) hipLaunchKernelGGL((k_tower<192, 2, 4, 96, 2, 96>), dim3(grid), dim3(512), lds, st, P);
                 else if (duo) hipLaunchKernelGGL((k_tower<192, 1, 4, 96, 2, 176, true, 2>), dim3(grid), dim3(256), lds, st, P);
                 else if (m->split == 1) hipLaunchKernelGGL((k_tower<192, 2, 4, 96, 2>), dim3(grid), dim3(512), lds, st, P);
