@@ -1020,12 +1020,12 @@ int mfma_create(const az_net_config& c, const NetLayout& L, const float* Pm, Mfm
             break;
         case 128:
             e = hipFuncSetAttribute((const void*)k_tower<128, 4, 2, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_tower<128, 2, 4, 64, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_tower<128, 2, 4, 64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e == hipSuccess && m->TB_small)
-                e = hipFuncSetAttribute((const void*)k_tower<128, 2, 4, 64, 1, 96>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                e = hipFuncSetAttribute((const void*)k_tower<128, 2, 4, 64, 3, 96>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)tower_lds_bytes(C, m->NH, m->TB_small, c.se_hidden, 96));
             if (e == hipSuccess && m->rows_main == 384)
-                e = hipFuncSetAttribute((const void*)k_tower<128, 2, 4, 64, 1, 384>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                e = hipFuncSetAttribute((const void*)k_tower<128, 2, 4, 64, 3, 384>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             break;
         case 192:
             e = hipFuncSetAttribute((const void*)k_tower<192, 4, 2, 96>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1314,9 +1314,9 @@ static int fused_forward(MfmaNet* m, const void* feat, int rows, const int* rows
                 else hipLaunchKernelGGL((k_tower<64, 4, 2, 32>), dim3(grid), dim3(512), lds, st, P);
                 break;
             case 128:
-                if (sm) hipLaunchKernelGGL((k_tower<128, 2, 4, 64, 1, 96>), dim3(grid), dim3(512), lds, st, P);
-                else if (m->rows_main == 384) hipLaunchKernelGGL((k_tower<128, 2, 4, 64, 1, 384>), dim3(grid), dim3(512), lds, st, P);
-                else if (m->split == 1) hipLaunchKernelGGL((k_tower<128, 2, 4, 64, 1>), dim3(grid), dim3(512), lds, st, P);
+                if (sm) hipLaunchKernelGGL((k_tower<128, 2, 4, 64, 3, 96>), dim3(grid), dim3(512), lds, st, P);
+                else if (m->rows_main == 384) hipLaunchKernelGGL((k_tower<128, 2, 4, 64, 3, 384>), dim3(grid), dim3(512), lds, st, P);
+                else if (m->split == 1) hipLaunchKernelGGL((k_tower<128, 2, 4, 64, 3>), dim3(grid), dim3(512), lds, st, P);
                 else hipLaunchKernelGGL((k_tower<128, 4, 2, 64>), dim3(grid), dim3(512), lds, st, P);
                 break;
             case 192:
