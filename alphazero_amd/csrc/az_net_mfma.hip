@@ -786,6 +786,7 @@ struct MfmaNet {
     std::vector<void*> retired;   // scratch buffers that were replaced by larger ones: launches already enqueued may still use
                                   // them, so they are only freed with the network (sizes grow geometrically: bounded waste)
     int TB_duo = 0;               // boards per workgroup of the two-workgroups-per-CU variant (176 rows, 256 threads; 0: none)
+    int small_rounds = 2;         // rounds of workgroups up to which the 96-row variant is chosen (AZ_TOWER_SMALL_ROUNDS overrides)
     bool small_lean = false;      // the 96-row variant as 256-thread workgroups, two per compute unit (192 channels)
     int TB_small = 0;             // boards per workgroup of the 96-row low-latency variant (0: this shape has none)
     bool device_choice = true;    // indirect forwards under a moderate bound launch the 96-row variant too, gated on the count
@@ -880,6 +881,8 @@ int mfma_create(const az_net_config& c, const NetLayout& L, const float* Pm, Mfm
     if (const char* du = getenv("AZ_TOWER_DUO")) if (atoi(du) == 0) m->TB_duo = 0;
     m->small_lean = m->TB_small > 0 && m->TB_duo > 0 && np <= 96;
     if (const char* sl = getenv("AZ_TOWER_SMALL_LEAN")) if (atoi(sl) == 0) m->small_lean = false;
+    m->small_rounds = (C == 64 || m->TB_duo > 0) ? 1 : 2;
+    if (const char* sr = getenv("AZ_TOWER_SMALL_ROUNDS")) m->small_rounds = std::max(1, atoi(sr));
     const int tiles_per_wave = C / 64;              // 2x4 waves: C/4 channels each
     const int slab_tiles = (m->split == 1 && (tiles_per_wave & 1)) ? tiles_per_wave : 0;   // channel tiles per wave when that count is odd
     const bool small_images = m->TB_small > 0 && m->split == 0;   // (only C == 64) pack the 2x4-wave images beside the main ones
@@ -1266,7 +1269,7 @@ static int fused_forward(MfmaNet* m, const void* feat, int rows, const int* rows
     // It keeps 5 k-steps of weight fragments in flight instead of 2 (a lone wave per SIMD has no other wave to cover the
     // L2 latency: forward of 1 / 40 / 96 / 160 / 256 boards 0.347 / 0.350 / 0.353 / 0.364 / 0.41 -> 0.320 / 0.330 / 0.342 / 0.360 / 0.41 ms).
     const bool lean_small = m->small_lean && !static_scratch_call;
-    const int small_rounds = (C == 64 || m->TB_duo > 0) ? 1 : 2;
+    const int small_rounds = m->small_rounds;
     const int small_rows = m->TB_small > 0 ? small_rounds * m->cus * m->TB_small : 0;   // most rows the 96-row variant is chosen for
     const bool small = rows <= small_rows;
     // Count on the device and a bound above that limit (a search that evaluates a repeated leaf once has about one row per
