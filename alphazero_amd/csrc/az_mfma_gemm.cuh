@@ -368,6 +368,8 @@ __device__ __forceinline__ void gemm_conv(f32x4 (&acc)[MI][NI], const uint4* __r
     }
 }
 
+template <int V> struct RingBase { static constexpr int value = V; };
+
 // The same convolution with the weight fragments read straight from the packed global image into registers (the
 // image is stored in fragment order, so a fragment is one coalesced 1 KiB load; the waves that share output channels
 // hit the same lines in the CU's vector cache). Nothing is staged through LDS and the activations are read-only
@@ -428,7 +430,10 @@ __device__ __forceinline__ void gemm_conv_gw(f32x4 (&acc)[MI][NI], const uint4* 
     // the k-step's NI weight loads after each of the first NI groups): left to itself the scheduler sinks the reads to
     // the end of the k-step and the first MFMA of the next one waits for LDS.
     bf16x8 a[MI], b[DEPTH + 1][NI];
-    static_assert(KPT % 2 == 0 && (KPT % (DEPTH + 1) == 0 || DEPTH == 1), "the fragment ring must keep static indices across taps");
+    constexpr int NB = DEPTH + 1;
+    // the ring of weight fragments keeps static indices when its period divides a tap's k-steps, or spans exactly two taps
+    // (64 channels: two k-steps per tap under a ring of four); the taps then go in pairs, and the odd last one starts at 0 again
+    static_assert(KPT % 2 == 0 && (KPT % NB == 0 || NB == 2 * KPT), "the fragment ring must keep static indices across taps");
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d)
 #pragma unroll
@@ -437,12 +442,12 @@ __device__ __forceinline__ void gemm_conv_gw(f32x4 (&acc)[MI][NI], const uint4* 
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) a[mi] = *(const bf16x8*)(act + apc[mi]);
     int s = 0;
-    for (int tap = 0; tap < ntaps; ++tap) {
+    auto one_tap = [&](int tap, auto base_c) {
+        constexpr int BASE = decltype(base_c)::value;   // ring position of the tap's first k-step
         tap_offsets(apn, tap + 1);
 #pragma unroll
         for (int u = 0; u < KPT; ++u, ++s) {
-            constexpr int NB = DEPTH + 1;
-            const int bc = u % NB, bn = (u + DEPTH) % NB;
+            const int bc = (BASE + u) % NB, bn = (BASE + u + DEPTH) % NB;
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) b[bn][ni] = wfrag(s + DEPTH, ni);
 #pragma unroll
@@ -461,6 +466,16 @@ __device__ __forceinline__ void gemm_conv_gw(f32x4 (&acc)[MI][NI], const uint4* 
         }
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) apc[mi] = apn[mi];
+    };
+    if constexpr (KPT % NB == 0) {
+        for (int tap = 0; tap < ntaps; ++tap) one_tap(tap, RingBase<0>{});
+    } else {
+        int tap = 0;
+        for (; tap + 2 <= ntaps; tap += 2) {
+            one_tap(tap, RingBase<0>{});
+            one_tap(tap + 1, RingBase<KPT>{});
+        }
+        if (tap < ntaps) one_tap(tap, RingBase<0>{});
     }
 }
 

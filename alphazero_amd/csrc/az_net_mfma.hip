@@ -30,6 +30,17 @@
 #include "az_net.h"
 #include "az_mfma_gemm.cuh"
 
+// k-steps of weight fragments in flight in the kernels that read them from global memory (the 192-channel ones: 2, or 5 in
+// the 96-row 256-thread form; see their instantiations)
+#ifndef AZ_GW128
+#define AZ_GW128 1       // 128 channels, 256- and 384-row kernels (3 measured the same on one box: 916 / 916 TFLOP/s at 4096 boards of 9x9)
+#endif
+#ifndef AZ_GW128S
+#define AZ_GW128S 3      // 128 channels, 96-row variant: a lone workgroup per compute unit (one board 0.271 -> 0.182 ms, 256 boards 0.286 -> 0.202)
+#endif
+#ifndef AZ_GW64S
+#define AZ_GW64S 3       // 64 channels, 96-row variant (256 boards 0.061 -> 0.058 ms)
+#endif
 #ifndef AZ_RING
 #define AZ_RING 6        // activation-fragment ring of the two-workgroups-per-CU tower (gemm_conv_ring)
 #endif
@@ -1018,17 +1029,17 @@ int mfma_create(const az_net_config& c, const NetLayout& L, const float* Pm, Mfm
             e = hipFuncSetAttribute((const void*)k_tower<64, 4, 2, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_tower<64, 2, 4, 32, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e == hipSuccess && m->TB_small)
-                e = hipFuncSetAttribute((const void*)k_tower<64, 2, 4, 32, 1, 96>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                e = hipFuncSetAttribute((const void*)k_tower<64, 2, 4, 32, AZ_GW64S, 96>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)tower_lds_bytes(C, m->NH, m->TB_small, c.se_hidden, 96));
             break;
         case 128:
             e = hipFuncSetAttribute((const void*)k_tower<128, 4, 2, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_tower<128, 2, 4, 64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_tower<128, 2, 4, 64, AZ_GW128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e == hipSuccess && m->TB_small)
-                e = hipFuncSetAttribute((const void*)k_tower<128, 2, 4, 64, 3, 96>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                e = hipFuncSetAttribute((const void*)k_tower<128, 2, 4, 64, AZ_GW128S, 96>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)tower_lds_bytes(C, m->NH, m->TB_small, c.se_hidden, 96));
             if (e == hipSuccess && m->rows_main == 384)
-                e = hipFuncSetAttribute((const void*)k_tower<128, 2, 4, 64, 3, 384>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                e = hipFuncSetAttribute((const void*)k_tower<128, 2, 4, 64, AZ_GW128, 384>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             break;
         case 192:
             e = hipFuncSetAttribute((const void*)k_tower<192, 4, 2, 96>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1312,14 +1323,14 @@ static int fused_forward(MfmaNet* m, const void* feat, int rows, const int* rows
         switch (C) {
             case 32: hipLaunchKernelGGL((k_tower<32, 8, 1, 32>), dim3(grid), dim3(512), lds, st, P); break;
             case 64:
-                if (sm) hipLaunchKernelGGL((k_tower<64, 2, 4, 32, 1, 96>), dim3(grid), dim3(512), lds, st, P);
+                if (sm) hipLaunchKernelGGL((k_tower<64, 2, 4, 32, AZ_GW64S, 96>), dim3(grid), dim3(512), lds, st, P);
                 else if (m->split == 1) hipLaunchKernelGGL((k_tower<64, 2, 4, 32, 1>), dim3(grid), dim3(512), lds, st, P);
                 else hipLaunchKernelGGL((k_tower<64, 4, 2, 32>), dim3(grid), dim3(512), lds, st, P);
                 break;
             case 128:
-                if (sm) hipLaunchKernelGGL((k_tower<128, 2, 4, 64, 3, 96>), dim3(grid), dim3(512), lds, st, P);
-                else if (m->rows_main == 384) hipLaunchKernelGGL((k_tower<128, 2, 4, 64, 3, 384>), dim3(grid), dim3(512), lds, st, P);
-                else if (m->split == 1) hipLaunchKernelGGL((k_tower<128, 2, 4, 64, 3>), dim3(grid), dim3(512), lds, st, P);
+                if (sm) hipLaunchKernelGGL((k_tower<128, 2, 4, 64, AZ_GW128S, 96>), dim3(grid), dim3(512), lds, st, P);
+                else if (m->rows_main == 384) hipLaunchKernelGGL((k_tower<128, 2, 4, 64, AZ_GW128, 384>), dim3(grid), dim3(512), lds, st, P);
+                else if (m->split == 1) hipLaunchKernelGGL((k_tower<128, 2, 4, 64, AZ_GW128>), dim3(grid), dim3(512), lds, st, P);
                 else hipLaunchKernelGGL((k_tower<128, 4, 2, 64>), dim3(grid), dim3(512), lds, st, P);
                 break;
             case 192:
