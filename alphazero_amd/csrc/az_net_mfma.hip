@@ -32,6 +32,9 @@
 
 // k-steps of weight fragments in flight in the kernels that read them from global memory (the 192-channel ones: 2, or 5 in
 // the 96-row 256-thread form; see their instantiations)
+#ifndef AZ_SE_LDS96
+#define AZ_SE_LDS96 1     // 0: the 96-row 256-thread form reads its squeeze-excite weights from global memory (A/B builds)
+#endif
 #ifndef AZ_GW128
 #define AZ_GW128 1       // 128 channels, 256- and 384-row kernels (3 measured the same on one box: 916 / 916 TFLOP/s at 4096 boards of 9x9)
 #endif
@@ -366,7 +369,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void k_tower(TowerParams P) {
     // The 96-row LEAN form has LDS to spare and mostly runs alone on its compute unit (few positions): its squeeze-excite
     // weights are staged in LDS like the 512-thread kernels' (reading them from global memory, which the 176-row form hides
     // behind the compute unit's other workgroup, cost 9 % of a lone workgroup's cycles in fc2 alone).
-    constexpr bool SE_LDS = LEAN && ROWS == 96;
+    constexpr bool SE_LDS = LEAN && ROWS == 96 && AZ_SE_LDS96;
     constexpr int RING = MI > AZ_RING ? AZ_RING : 4;   // activation-fragment ring of gemm_conv_ring: fewer than the row tiles a wave owns
     constexpr int NV = MI * (NI / 2) + ((NI & 1) ? (MI + 1) / 2 : 0);  // 16-byte vectors of packed bf16 residual per thread
     static_assert(ROWS % (WM * 16) == 0 && NIH % 2 == 0, "whole row tiles per wave; head channel tiles are stored in pairs");
