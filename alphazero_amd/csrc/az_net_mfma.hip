@@ -893,7 +893,7 @@ int mfma_create(const az_net_config& c, const NetLayout& L, const float* Pm, Mfm
     // where whole boards fill at least 90 % of its 176 rows (duo_fill_ok); AZ_TOWER_DUO=0 switches it off
     m->TB_duo = (fused && m->split == 1 && C == 192 && duo_fill_ok(np)) ? 176 / np : 0;
     if (const char* du = getenv("AZ_TOWER_DUO")) if (atoi(du) == 0) m->TB_duo = 0;
-    m->small_lean = m->TB_small > 0 && m->TB_duo > 0 && np <= 96;
+    m->small_lean = m->TB_small > 0 && (m->TB_duo > 0 || (C == 128 && m->split == 1)) && np <= 96;
     if (const char* sl = getenv("AZ_TOWER_SMALL_LEAN")) if (atoi(sl) == 0) m->small_lean = false;
     m->small_rounds = (C == 64 || m->TB_duo > 0) ? 1 : 2;
     if (const char* sr = getenv("AZ_TOWER_SMALL_ROUNDS")) m->small_rounds = std::max(1, atoi(sr));
@@ -1041,6 +1041,9 @@ int mfma_create(const az_net_config& c, const NetLayout& L, const float* Pm, Mfm
             if (e == hipSuccess && m->TB_small)
                 e = hipFuncSetAttribute((const void*)k_tower<128, 2, 4, 64, AZ_GW128S, 96>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)tower_lds_bytes(C, m->NH, m->TB_small, c.se_hidden, 96));
+            if (e == hipSuccess && m->small_lean)
+                e = hipFuncSetAttribute((const void*)k_tower<128, 1, 4, 64, AZ_GW128S, 96, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)tower_lds_bytes(C, m->NH, m->TB_small, c.se_hidden, 96, true));
             if (e == hipSuccess && m->rows_main == 384)
                 e = hipFuncSetAttribute((const void*)k_tower<128, 2, 4, 64, AZ_GW128, 384>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             break;
@@ -1331,7 +1334,8 @@ static int fused_forward(MfmaNet* m, const void* feat, int rows, const int* rows
                 else hipLaunchKernelGGL((k_tower<64, 4, 2, 32>), dim3(grid), dim3(512), lds, st, P);
                 break;
             case 128:
-                if (sm) hipLaunchKernelGGL((k_tower<128, 2, 4, 64, AZ_GW128S, 96>), dim3(grid), dim3(512), lds, st, P);
+                if (sm && lean_small) hipLaunchKernelGGL((k_tower<128, 1, 4, 64, AZ_GW128S, 96, true, 2>), dim3(grid), dim3(256), lds, st, P);
+                else if (sm) hipLaunchKernelGGL((k_tower<128, 2, 4, 64, AZ_GW128S, 96>), dim3(grid), dim3(512), lds, st, P);
                 else if (m->rows_main == 384) hipLaunchKernelGGL((k_tower<128, 2, 4, 64, AZ_GW128, 384>), dim3(grid), dim3(512), lds, st, P);
                 else if (m->split == 1) hipLaunchKernelGGL((k_tower<128, 2, 4, 64, AZ_GW128>), dim3(grid), dim3(512), lds, st, P);
                 else hipLaunchKernelGGL((k_tower<128, 4, 2, 64>), dim3(grid), dim3(512), lds, st, P);
