@@ -41,6 +41,9 @@
 #ifndef AZ_GW128S
 #define AZ_GW128S 3      // 128 channels, 96-row variant: a lone workgroup per compute unit (one board 0.271 -> 0.182 ms, 256 boards 0.286 -> 0.202)
 #endif
+#ifndef AZ_GW128D
+#define AZ_GW128D 3      // 128 channels, two 176-row workgroups per compute unit
+#endif
 #ifndef AZ_GW64S
 #define AZ_GW64S 3       // 64 channels, 96-row variant (256 boards 0.061 -> 0.058 ms)
 #endif
@@ -370,7 +373,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void k_tower(TowerParams P) {
     // weights are staged in LDS like the 512-thread kernels' (reading them from global memory, which the 176-row form hides
     // behind the compute unit's other workgroup, cost 9 % of a lone workgroup's cycles in fc2 alone).
     constexpr bool SE_LDS = LEAN && ROWS == 96 && AZ_SE_LDS96;
-    constexpr int RING = MI > AZ_RING ? AZ_RING : 4;   // activation-fragment ring of gemm_conv_ring: fewer than the row tiles a wave owns
+    constexpr int RING = (MI > AZ_RING && ((C / 32) * MI) % AZ_RING == 0) ? AZ_RING : 4;   // activation-fragment ring of gemm_conv_ring: fewer than the row tiles a wave owns
     constexpr int NV = MI * (NI / 2) + ((NI & 1) ? (MI + 1) / 2 : 0);  // 16-byte vectors of packed bf16 residual per thread
     static_assert(ROWS % (WM * 16) == 0 && NIH % 2 == 0, "whole row tiles per wave; head channel tiles are stored in pairs");
     static_assert(NW * 16 * MIH * (2 * NH + 16) <= ROWS * STRIDE, "the head activations of every wave's row tiles must fit the activation image");
@@ -800,6 +803,7 @@ struct MfmaNet {
     std::vector<void*> retired;   // scratch buffers that were replaced by larger ones: launches already enqueued may still use
                                   // them, so they are only freed with the network (sizes grow geometrically: bounded waste)
     int TB_duo = 0;               // boards per workgroup of the two-workgroups-per-CU variant (176 rows, 256 threads; 0: none)
+    bool duo_above_one_round = false;   // the two-per-CU kernel only where the 256-row kernel would need a second round of workgroups (128 channels)
     int small_rounds = 2;         // rounds of workgroups up to which the 96-row variant is chosen (AZ_TOWER_SMALL_ROUNDS overrides)
     bool small_lean = false;      // the 96-row variant as 256-thread workgroups, two per compute unit (192 channels)
     int TB_small = 0;             // boards per workgroup of the 96-row low-latency variant (0: this shape has none)
@@ -891,11 +895,17 @@ int mfma_create(const az_net_config& c, const NetLayout& L, const float* Pm, Mfm
     if (const char* sm = getenv("AZ_TOWER_SMALL")) if (atoi(sm) == 0) m->TB_small = 0;
     // two 256-thread workgroups of two boards per compute unit (192 channels, global-weights form)
     // where whole boards fill at least 90 % of its 176 rows (duo_fill_ok); AZ_TOWER_DUO=0 switches it off
-    m->TB_duo = (fused && m->split == 1 && C == 192 && duo_fill_ok(np)) ? 176 / np : 0;
+    // 128 channels on boards up to 9x9 have the two-per-CU kernel too, from the row count on where the 256-row kernel needs
+    // a second round of workgroups (same box, 9x9 x 10 blocks, TFLOP/s against the 256-row kernel: 4096 boards 1 125 / 922,
+    // 1024 boards 979 / 698, 768 boards 840 / 836, 600 boards 700 / 750). AZ_TOWER_DUO128=0: off, =2: at every row count.
+    const int duo128_mode = getenv("AZ_TOWER_DUO128") ? atoi(getenv("AZ_TOWER_DUO128")) : 1;
+    const bool duo128 = C == 128 && c.board_size <= 9 && duo128_mode != 0;
+    m->duo_above_one_round = duo128 && duo128_mode != 2;
+    m->TB_duo = (fused && m->split == 1 && (C == 192 || duo128) && duo_fill_ok(np)) ? 176 / np : 0;
     if (const char* du = getenv("AZ_TOWER_DUO")) if (atoi(du) == 0) m->TB_duo = 0;
     m->small_lean = m->TB_small > 0 && (m->TB_duo > 0 || (C == 128 && m->split == 1)) && np <= 96;
     if (const char* sl = getenv("AZ_TOWER_SMALL_LEAN")) if (atoi(sl) == 0) m->small_lean = false;
-    m->small_rounds = (C == 64 || m->TB_duo > 0) ? 1 : 2;
+    m->small_rounds = (C == 64 || (C == 192 && m->TB_duo > 0)) ? 1 : 2;
     if (const char* sr = getenv("AZ_TOWER_SMALL_ROUNDS")) m->small_rounds = std::max(1, atoi(sr));
     const int tiles_per_wave = C / 64;              // 2x4 waves: C/4 channels each
     const int slab_tiles = (m->split == 1 && (tiles_per_wave & 1)) ? tiles_per_wave : 0;   // channel tiles per wave when that count is odd
@@ -1044,6 +1054,9 @@ int mfma_create(const az_net_config& c, const NetLayout& L, const float* Pm, Mfm
             if (e == hipSuccess && m->small_lean)
                 e = hipFuncSetAttribute((const void*)k_tower<128, 1, 4, 64, AZ_GW128S, 96, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)tower_lds_bytes(C, m->NH, m->TB_small, c.se_hidden, 96, true));
+            if (e == hipSuccess && m->TB_duo)
+                e = hipFuncSetAttribute((const void*)k_tower<128, 1, 4, 64, AZ_GW128D, 176, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)tower_lds_bytes(C, m->NH, m->TB_duo, c.se_hidden, 176, true));
             if (e == hipSuccess && m->rows_main == 384)
                 e = hipFuncSetAttribute((const void*)k_tower<128, 2, 4, 64, AZ_GW128, 384>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             break;
@@ -1307,7 +1320,7 @@ static int fused_forward(MfmaNet* m, const void* feat, int rows, const int* rows
     int grid = 0;
     for (int pass = both ? 0 : 1; pass < 2; ++pass) {
         const bool sm = both ? pass == 0 : small;
-        duo = !sm && m->TB_duo > 0 && !static_scratch_call;
+        duo = !sm && m->TB_duo > 0 && (!m->duo_above_one_round || rows > m->TB * m->cus) && !static_scratch_call;
         const int TB = sm ? m->TB_small : duo ? m->TB_duo : m->TB;
         P = m->P;
         P.rows = rows; P.feat = (const uint16_t*)feat; P.hq = hq; P.stamps = nullptr; P.xres = xres; P.rows_dev = rows_dev;
@@ -1336,6 +1349,7 @@ static int fused_forward(MfmaNet* m, const void* feat, int rows, const int* rows
             case 128:
                 if (sm && lean_small) hipLaunchKernelGGL((k_tower<128, 1, 4, 64, AZ_GW128S, 96, true, 2>), dim3(grid), dim3(256), lds, st, P);
                 else if (sm) hipLaunchKernelGGL((k_tower<128, 2, 4, 64, AZ_GW128S, 96>), dim3(grid), dim3(512), lds, st, P);
+                else if (duo) hipLaunchKernelGGL((k_tower<128, 1, 4, 64, AZ_GW128D, 176, true, 2>), dim3(grid), dim3(256), lds, st, P);
                 else if (m->rows_main == 384) hipLaunchKernelGGL((k_tower<128, 2, 4, 64, AZ_GW128, 384>), dim3(grid), dim3(512), lds, st, P);
                 else if (m->split == 1) hipLaunchKernelGGL((k_tower<128, 2, 4, 64, AZ_GW128>), dim3(grid), dim3(512), lds, st, P);
                 else hipLaunchKernelGGL((k_tower<128, 4, 2, 64>), dim3(grid), dim3(512), lds, st, P);

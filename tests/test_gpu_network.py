@@ -139,8 +139,10 @@ def test_bf16_exact_integer_network(path, kw, rows, small, monkeypatch):
         monkeypatch.setenv("AZ_TOWER_SMALL", "0")       # few rows would otherwise all go through the 96-row variant
         if small == "256_row_kernel":
             monkeypatch.setenv("AZ_TOWER_DUO", "0")     # 192 channels on 9x9 / 5x5 otherwise run two 176-row workgroups per CU
-        elif kw["channels"] != 192 or kw["board_size"] not in (5, 9, 11, 12, 13):
-            pytest.skip("the two-workgroups-per-CU kernel serves 192 channels on 11x11 to 13x13, 9x9 and 5x5")
+        elif not ((kw["channels"] == 192 and kw["board_size"] in (5, 9, 11, 12, 13)) or (kw["channels"] == 128 and kw["board_size"] in (5, 9))):
+            pytest.skip("the two-workgroups-per-CU kernel serves 192 channels on 11x11 to 13x13, 9x9 and 5x5, and 128 channels on 9x9 and 5x5")
+        else:
+            monkeypatch.setenv("AZ_TOWER_DUO128", "2")  # 128 channels: at every row count, not only above one round of the 256-row kernel
     net, x, lg_want, v_want = exactnet.find_exact_net(kw, path, rows)
     dev = torch.device("cuda:0")
     nn = net.to(dev).native("bf16", shared=False)
@@ -184,7 +186,7 @@ def test_bf16_small_and_large_batches_agree_bitwise():
         nn = net.to(dev).native("bf16", shared=False)
         f = _to_nhwc_bf16(x).to(dev)
         lg_all, v_all = nn(f)                                   # 1400 rows: 176-row or 256-row kernel
-        if kw["channels"] == 192 and n == 9:
+        if kw["channels"] in (128, 192) and n == 9:
             import os
             os.environ["AZ_TOWER_DUO"] = "0"
             try:
