@@ -841,7 +841,7 @@ static bool fused_supported(const az_net_config& c) {
     // above 9x9: 192 channels where one board fills the 176 rows of a two-per-CU workgroup well enough (11x11 to 13x13)
     // 17x17 to 19x19: 128 channels, one board in a 384-row workgroup (its activation image, 108 KB, still fits the LDS)
     const int np = c.board_size * c.board_size;
-    const bool bok = c.board_size <= 9 || (c.channels == 192 && duo_fill_ok(np) && !getenv("AZ_NO_FUSED_13")) ||
+    const bool bok = c.board_size <= 9 || ((c.channels == 192 || c.channels == 128) && duo_fill_ok(np) && !getenv("AZ_NO_FUSED_13")) ||
                      (c.channels == 128 && np > 256 && np <= 384 && np * 4 >= 384 * 3 && !getenv("AZ_NO_FUSED_19"));
     return cok && bok && c.board_size >= 2 && c.in_planes <= 64;
 }
@@ -899,8 +899,8 @@ int mfma_create(const az_net_config& c, const NetLayout& L, const float* Pm, Mfm
     // a second round of workgroups (same box, 9x9 x 10 blocks, TFLOP/s against the 256-row kernel: 4096 boards 1 125 / 922,
     // 1024 boards 979 / 698, 768 boards 840 / 836, 600 boards 700 / 750). AZ_TOWER_DUO128=0: off, =2: at every row count.
     const int duo128_mode = getenv("AZ_TOWER_DUO128") ? atoi(getenv("AZ_TOWER_DUO128")) : 1;
-    const bool duo128 = C == 128 && c.board_size <= 9 && duo128_mode != 0;
-    m->duo_above_one_round = duo128 && duo128_mode != 2;
+    const bool duo128 = C == 128 && (duo128_mode != 0 || c.board_size > 9);   // 11x11 to 13x13: one board per workgroup, as with 192 channels
+    m->duo_above_one_round = duo128 && duo128_mode != 2 && c.board_size <= 9;
     m->TB_duo = (fused && m->split == 1 && (C == 192 || duo128) && duo_fill_ok(np)) ? 176 / np : 0;
     if (const char* du = getenv("AZ_TOWER_DUO")) if (atoi(du) == 0) m->TB_duo = 0;
     m->small_lean = m->TB_small > 0 && (m->TB_duo > 0 || (C == 128 && m->split == 1)) && np <= 96;

@@ -119,6 +119,7 @@ EXACT = [("fused", dict(board_size=9, channels=192, num_blocks=12), 40), ("fused
          ("fused", dict(board_size=5, channels=192, num_blocks=2, value_hidden_dim=64), 30),
          ("fused", dict(board_size=13, channels=192, num_blocks=2), 7), ("fused", dict(board_size=13, channels=192, num_blocks=1, use_se=False, history_len=4), 2),
          ("fused", dict(board_size=11, channels=192, num_blocks=2), 6), ("fused", dict(board_size=12, channels=192, num_blocks=2), 5),
+         ("fused", dict(board_size=13, channels=128, num_blocks=2), 7), ("fused", dict(board_size=11, channels=128, num_blocks=2, use_se=False), 6),
          ("fused", dict(board_size=19, channels=128, num_blocks=2), 4), ("fused", dict(board_size=17, channels=128, num_blocks=2, use_se=False), 3),
          ("layers", dict(board_size=13, channels=64, num_blocks=2), 5), ("layers", dict(board_size=15, channels=128, num_blocks=2), 4),
          ("layers", dict(board_size=19, channels=256, num_blocks=3), 3), ("layers", dict(board_size=9, channels=256, num_blocks=2, value_hidden_dim=64), 9),
@@ -139,7 +140,7 @@ def test_bf16_exact_integer_network(path, kw, rows, small, monkeypatch):
         monkeypatch.setenv("AZ_TOWER_SMALL", "0")       # few rows would otherwise all go through the 96-row variant
         if small == "256_row_kernel":
             monkeypatch.setenv("AZ_TOWER_DUO", "0")     # 192 channels on 9x9 / 5x5 otherwise run two 176-row workgroups per CU
-        elif not ((kw["channels"] == 192 and kw["board_size"] in (5, 9, 11, 12, 13)) or (kw["channels"] == 128 and kw["board_size"] in (5, 9))):
+        elif not ((kw["channels"] == 192 and kw["board_size"] in (5, 9, 11, 12, 13)) or (kw["channels"] == 128 and kw["board_size"] in (5, 9, 11, 13))):
             pytest.skip("the two-workgroups-per-CU kernel serves 192 channels on 11x11 to 13x13, 9x9 and 5x5, and 128 channels on 9x9 and 5x5")
         else:
             monkeypatch.setenv("AZ_TOWER_DUO128", "2")  # 128 channels: at every row count, not only above one round of the 256-row kernel
@@ -309,15 +310,16 @@ def test_fused_tower_on_19x19_128_channels(monkeypatch):
         nn.forward_static(f, lb, vb)        # the entry point without allocations serves boards up to 9x9
 
 
-def test_fused_tower_on_13x13(monkeypatch):
-    """13x13 with 192 channels runs the fused tower (one board of 169 points per two-per-CU workgroup): within 1e-2 of
+@pytest.mark.parametrize("channels", [192, 128])
+def test_fused_tower_on_13x13(channels, monkeypatch):
+    """13x13 with 192 (or 128) channels runs the fused tower (one board of 169 points per two-per-CU workgroup): within 1e-2 of
     the float32 torch module on default-initialised weights, a position's output independent of its neighbours in the
     batch and of the kernel (two-per-CU or 256-row), and close to what the layer-by-layer path gives for the same weights
     (AZ_NO_FUSED_13=1; another summation order, so not the same bits)."""
     from alphazero_amd.model import AlphaZeroNet
     import stubnets
     torch.manual_seed(13)
-    net = AlphaZeroNet(board_size=13, channels=192, num_blocks=3).eval()
+    net = AlphaZeroNet(board_size=13, channels=channels, num_blocks=3).eval()
     x = stubnets.synthetic_planes(21, 21, 13, seed=4)
     with torch.inference_mode():
         lg_t, v_t = net(torch.from_numpy(x))
