@@ -57,7 +57,7 @@ int fail(int code, const std::string& msg);
 
 struct TowerParams {
     int n, np, TB, rows, blocks, use_se, hid, cin_pad, q;
-    unsigned recip_np;           // floor(row / np) == (row * recip_np) >> 16 for row < 512
+    unsigned recip_np;           // floor(row / np) == (row * recip_np) >> 16 for every row of a workgroup (checked at creation)
     unsigned recip_n;            // floor(p / n) == (p * recip_n) >> 16 for p < 512
     const uint16_t* feat;        // [rows][np][cin_pad] bf16
     const uint4* w_stem;         // packed tiles
@@ -843,7 +843,9 @@ static bool fused_supported(const az_net_config& c) {
     const int np = c.board_size * c.board_size;
     const bool bok = c.board_size <= 9 || ((c.channels == 192 || c.channels == 128) && duo_fill_ok(np) && !getenv("AZ_NO_FUSED_13")) ||
                      (c.channels == 128 && np > 256 && np <= 384 && np * 4 >= 384 * 3 && !getenv("AZ_NO_FUSED_19"));
-    return cok && bok && c.board_size >= 2 && c.in_planes <= 64;
+    // 14x14 to 16x16: 128 channels, one board in a 256-row workgroup of the 2x4-wave kernel (at least three quarters of its rows)
+    const bool bok16 = c.channels == 128 && np > 176 && np <= 256 && np * 4 >= 256 * 3 && !getenv("AZ_NO_FUSED_16");
+    return cok && (bok || bok16) && c.board_size >= 2 && c.in_planes <= 64;
 }
 bool mfma_supported(const az_net_config& c) { return (fused_supported(c) || layers_supported(c)) && c.value_hidden >= 1; }
 bool mfma_is_fused(const MfmaNet* m) { return m->layers == nullptr; }
@@ -922,7 +924,7 @@ int mfma_create(const az_net_config& c, const NetLayout& L, const float* Pm, Mfm
     P.cin_pad = m->cin_pad; P.q = q;
     P.recip_np = (65536 + np - 1) / np;
     P.recip_n = (65536 + c.board_size - 1) / c.board_size;
-    for (int row = 0; fused && row < 512; ++row)
+    for (int row = 0; fused && row < m->rows_main; ++row)   // every row index a workgroup of any variant can hold
         if ((((unsigned)row * P.recip_np) >> 16 != (unsigned)(row / np)) || (((unsigned)row * P.recip_n) >> 16 != (unsigned)(row / c.board_size))) {
             delete m;
             return fail(AZ_ERR_ARG, "reciprocal division check failed");

@@ -119,6 +119,7 @@ EXACT = [("fused", dict(board_size=9, channels=192, num_blocks=12), 40), ("fused
          ("fused", dict(board_size=5, channels=192, num_blocks=2, value_hidden_dim=64), 30),
          ("fused", dict(board_size=13, channels=192, num_blocks=2), 7), ("fused", dict(board_size=13, channels=192, num_blocks=1, use_se=False, history_len=4), 2),
          ("fused", dict(board_size=11, channels=192, num_blocks=2), 6), ("fused", dict(board_size=12, channels=192, num_blocks=2), 5),
+         ("fused", dict(board_size=15, channels=128, num_blocks=2), 4), ("fused", dict(board_size=16, channels=128, num_blocks=1, use_se=False), 3),
          ("fused", dict(board_size=13, channels=128, num_blocks=2), 7), ("fused", dict(board_size=11, channels=128, num_blocks=2, use_se=False), 6),
          ("fused", dict(board_size=19, channels=128, num_blocks=2), 4), ("fused", dict(board_size=17, channels=128, num_blocks=2, use_se=False), 3),
          ("layers", dict(board_size=13, channels=64, num_blocks=2), 5), ("layers", dict(board_size=15, channels=128, num_blocks=2), 4),
@@ -134,6 +135,8 @@ def test_bf16_exact_integer_network(path, kw, rows, small, monkeypatch):
     whatever its tiling or summation order. The kernels must equal the emulation exactly on every row, including the
     ragged last board group; the value (a tanh) to 2e-6."""
     import exactnet
+    if path == "layers":
+        monkeypatch.setenv("AZ_NO_FUSED_16", "1")   # 128 channels on 14x14 to 16x16 would otherwise take the fused tower
     if small != "small_variant":
         if path != "fused" or kw["channels"] < 64:
             pytest.skip("only the fused 64/128/192-channel towers have a second (96-row, low-latency) kernel to switch off")
@@ -245,11 +248,12 @@ LAYERED = [dict(board_size=13, channels=64, num_blocks=2), dict(board_size=15, c
 
 
 @pytest.mark.parametrize("kw", LAYERED, ids=lambda k: f"n{k['board_size']}_c{k['channels']}")
-def test_bf16_layer_path(kw):
+def test_bf16_layer_path(kw, monkeypatch):
     """Boards above 9x9 and 256-channel towers run layer by layer (activations in HBM): same 1e-2 bound against the
     float32 torch module, same independence of a position's output from its neighbours in the batch."""
     from alphazero_amd.model import AlphaZeroNet
     import stubnets
+    monkeypatch.setenv("AZ_NO_FUSED_16", "1")      # 128 channels on 14x14 to 16x16 would otherwise take the fused tower
     torch.manual_seed(11)
     net = AlphaZeroNet(**kw).eval()
     n, c = kw["board_size"], 2 * kw.get("history_len", 8) + 5
