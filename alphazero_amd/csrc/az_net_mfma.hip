@@ -843,8 +843,8 @@ static bool fused_supported(const az_net_config& c) {
     const int np = c.board_size * c.board_size;
     const bool bok = c.board_size <= 9 || ((c.channels == 192 || c.channels == 128) && duo_fill_ok(np) && !getenv("AZ_NO_FUSED_13")) ||
                      (c.channels == 128 && np > 256 && np <= 384 && np * 4 >= 384 * 3 && !getenv("AZ_NO_FUSED_19"));
-    // 14x14 to 16x16: 128 channels, one board in a 256-row workgroup of the 2x4-wave kernel (at least three quarters of its rows)
-    const bool bok16 = c.channels == 128 && np > 176 && np <= 256 && np * 4 >= 256 * 3 && !getenv("AZ_NO_FUSED_16");
+    // 14x14 to 16x16: 128 or 192 channels, one board in a 256-row workgroup of the 2x4-wave kernel (at least three quarters of its rows)
+    const bool bok16 = (c.channels == 128 || c.channels == 192) && np > 176 && np <= 256 && np * 4 >= 256 * 3 && !getenv("AZ_NO_FUSED_16");
     return cok && (bok || bok16) && c.board_size >= 2 && c.in_planes <= 64;
 }
 bool mfma_supported(const az_net_config& c) { return (fused_supported(c) || layers_supported(c)) && c.value_hidden >= 1; }

@@ -119,7 +119,8 @@ EXACT = [("fused", dict(board_size=9, channels=192, num_blocks=12), 40), ("fused
          ("fused", dict(board_size=5, channels=192, num_blocks=2, value_hidden_dim=64), 30),
          ("fused", dict(board_size=13, channels=192, num_blocks=2), 7), ("fused", dict(board_size=13, channels=192, num_blocks=1, use_se=False, history_len=4), 2),
          ("fused", dict(board_size=11, channels=192, num_blocks=2), 6), ("fused", dict(board_size=12, channels=192, num_blocks=2), 5),
-         ("fused", dict(board_size=15, channels=128, num_blocks=2), 4), ("fused", dict(board_size=16, channels=128, num_blocks=1, use_se=False), 3),
+         ("fused", dict(board_size=15, channels=128, num_blocks=2), 4), ("fused", dict(board_size=15, channels=192, num_blocks=2), 3),
+         ("fused", dict(board_size=14, channels=192, num_blocks=1, use_se=False, history_len=4), 2), ("fused", dict(board_size=16, channels=128, num_blocks=1, use_se=False), 3),
          ("fused", dict(board_size=13, channels=128, num_blocks=2), 7), ("fused", dict(board_size=11, channels=128, num_blocks=2, use_se=False), 6),
          ("fused", dict(board_size=19, channels=128, num_blocks=2), 4), ("fused", dict(board_size=17, channels=128, num_blocks=2, use_se=False), 3),
          ("layers", dict(board_size=13, channels=64, num_blocks=2), 5), ("layers", dict(board_size=15, channels=128, num_blocks=2), 4),
