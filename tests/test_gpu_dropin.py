@@ -284,7 +284,7 @@ def test_lockstep_selfplay_on_19x19_layer_path():
     assert logs[0][1]["nn_rows"] == logs[1][1]["nn_rows"]
 
 
-@pytest.mark.parametrize("n,channels", [(13, 192), (19, 128), (13, 128)])
+@pytest.mark.parametrize("n,channels", [(13, 192), (19, 128), (13, 128), (15, 192), (16, 128)])
 def test_lockstep_selfplay_on_large_board_fused_tower(n, channels):
     """13x13 with 192 channels and 19x19 with 128: the fused tower serves the search (one board per workgroup of 176 or
     384 rows); a few lockstep moves with the batches enqueued without round trips equal the same moves with one round
