@@ -110,6 +110,42 @@ def deterministic_state_dict(shapes: dict[str, tuple[int, ...]], seed: int) -> d
     return out
 
 
+def realistic_state_dict(shapes: dict[str, tuple[int, ...]], seed: int, head_gain: float = 4.0) -> dict[str, np.ndarray]:
+    """Reproducible float32 values at the scale a freshly initialised (or lightly trained) network has.
+
+    Conv/linear weights and linear/conv biases ~ U(-1/sqrt(fan_in), 1/sqrt(fan_in)) (what torch.nn's default
+    initialisers draw, model.py:9-87 uses them unchanged); BatchNorm weight in [0.8, 1.2], bias in [-0.1, 0.1],
+    running_mean in [-0.2, 0.2], running_var in [0.6, 1.4]. The two output layers (policy_fc.weight, value_head.6.weight)
+    are then scaled by `head_gain`, so that logits span a few units as a trained network's do instead of a few tenths.
+    A bf16 evaluation of such a network is well conditioned. Keys are visited in sorted order.
+    """
+    rng = np.random.Generator(np.random.PCG64(seed))
+    out: dict[str, np.ndarray] = {}
+    fan = {k: int(np.prod(s[1:])) for k, s in shapes.items() if len(s) > 1}
+    for key in sorted(shapes):
+        shp = tuple(shapes[key])
+        if key.endswith("num_batches_tracked"):
+            out[key] = np.array(7, dtype=np.int64)
+        elif key.endswith("running_mean"):
+            out[key] = rng.uniform(-0.2, 0.2, shp).astype(np.float32)
+        elif key.endswith("running_var"):
+            out[key] = rng.uniform(0.6, 1.4, shp).astype(np.float32)
+        elif len(shp) == 1 and key.endswith("weight"):  # BN gamma
+            out[key] = rng.uniform(0.8, 1.2, shp).astype(np.float32)
+        elif len(shp) == 1 and key[: -len("bias")] + "weight" in fan:   # bias of a conv / linear layer
+            b = 1.0 / np.sqrt(fan[key[: -len("bias")] + "weight"])
+            out[key] = rng.uniform(-b, b, shp).astype(np.float32)
+        elif len(shp) == 1:  # BN beta
+            out[key] = rng.uniform(-0.1, 0.1, shp).astype(np.float32)
+        else:
+            b = 1.0 / np.sqrt(fan[key])
+            out[key] = rng.uniform(-b, b, shp).astype(np.float32)
+    for key in ("policy_fc.weight", "value_head.6.weight"):
+        if key in out:
+            out[key] = out[key] * np.float32(head_gain)
+    return out
+
+
 def synthetic_planes(b: int, c: int, n: int, seed: int) -> np.ndarray:
     """Feature-plane-like float32 input: sparse 0/1 planes plus two constant fraction planes."""
     rng = np.random.Generator(np.random.PCG64(seed))

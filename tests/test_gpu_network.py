@@ -6,7 +6,7 @@ import pytest
 import torch
 
 import golden_io
-from tests_common import GOLDEN_NETS, build_golden_net
+from tests_common import GOLDEN_NETS, REALISTIC_NETS, build_golden_net, build_realistic_net
 
 pytestmark = pytest.mark.gpu
 
@@ -110,6 +110,44 @@ def test_bf16_path_golden_weights(name):
         allow = 4.0 * s[i] + floor[i]
         assert k[i] <= allow, (i, k[i], allow)
         assert e[i] <= max(1e-2 if i < 2 else 0.0, b[i] + allow), (i, e[i], b[i], allow)
+
+
+# which switch sends a realistic-scale network to the layer-by-layer kernels (None: it runs there anyway, or has no such path)
+_LAYER_SWITCH = {"real_n13_c192_b6": "AZ_NO_FUSED_13", "real_n19_c128_b3": "AZ_NO_FUSED_19"}
+
+
+@pytest.mark.parametrize("name", REALISTIC_NETS)
+def test_kernels_vs_upstream_outputs_on_realistic_weights(name, monkeypatch):
+    """Weights at the scale of a freshly initialised network (|logit| up to 2.2, stubnets.realistic_state_dict); the
+    expected outputs are the upstream module's own (tests/golden/network_realistic.npz). The bf16 kernels, on whichever of
+    the two bf16 paths serves the shape (and on the layer-by-layer path too where a switch selects it), are within 1e-2
+    abs of them on logits, probabilities and value; the float32 kernels within 1e-5. Includes the 19x19 256-channel x 20
+    tower at full depth."""
+    net, x, kw, lg_ref, v_ref = build_realistic_net(name)
+    lg_ref, v_ref = torch.from_numpy(lg_ref), torch.from_numpy(v_ref)
+    dev = torch.device("cuda:0")
+    net = net.to(dev)
+    lg32, v32 = net.native("f32")(torch.from_numpy(x).to(dev))
+    e32 = float((lg32.cpu() - lg_ref).abs().max()), float((v32.cpu() - v_ref).abs().max())
+    print(f"{name}: float32 kernels vs upstream: logits {e32[0]:.3g} value {e32[1]:.3g}")
+    assert e32[0] <= 1e-5 * max(1.0, float(lg_ref.abs().max())) and e32[1] <= 1e-5
+    if kw["channels"] == 32 and kw["board_size"] > 9:
+        return
+    f = _to_nhwc_bf16(x).to(dev)
+    paths = [None] + ([_LAYER_SWITCH[name]] if name in _LAYER_SWITCH else [])
+    for switch in paths:
+        if switch:
+            monkeypatch.setenv(switch, "1")
+        nn = net.native("bf16", shared=False)
+        if switch:
+            monkeypatch.delenv(switch)
+            assert not nn.fused
+        lg, v = nn(f)
+        lg, v = lg.cpu(), v.cpu()
+        e = (float((lg.softmax(1) - lg_ref.softmax(1)).abs().max()), float((v - v_ref).abs().max()), float((lg - lg_ref).abs().max()))
+        print(f"{name} [{'fused' if nn.fused else 'layers'}]: bf16 kernels vs upstream: prob {e[0]:.3g} value {e[1]:.3g} logit {e[2]:.3g} "
+              f"(|logit| max {float(lg_ref.abs().max()):.3g})")
+        assert e[0] <= 1e-2 and e[1] <= 1e-2 and e[2] <= 1e-2
 
 
 EXACT = [("fused", dict(board_size=9, channels=192, num_blocks=12), 40), ("fused", dict(board_size=9, channels=128, num_blocks=3), 40),

@@ -9,7 +9,7 @@ import torch
 import golden_io
 import stubnets
 from alphazero_amd.model import AlphaZeroNet, PolicyValueNet
-from tests_common import build_golden_net, GOLDEN_NETS
+from tests_common import build_golden_net, build_realistic_net, GOLDEN_NETS, REALISTIC_NETS
 
 
 def test_alias():
@@ -30,6 +30,16 @@ def test_state_dict_contract_and_outputs(name):
     scale = max(1.0, float(np.abs(z[f"{name}/logits"]).max()))   # float32 summation order varies with the thread count
     assert np.abs(lg.numpy() - z[f"{name}/logits"]).max() < 1e-5 * scale
     assert np.abs(v.numpy() - z[f"{name}/value"]).max() < 2e-5
+
+
+@pytest.mark.parametrize("name", [n for n in REALISTIC_NETS if n != "real_n19_c256_b20"])   # the 20-block tower: GPU tests only (CPU time)
+def test_realistic_weights_outputs(name):
+    """The host module with the realistic-scale generated weights reproduces the upstream module's stored outputs."""
+    net, x, kw, lg_ref, v_ref = build_realistic_net(name)
+    with torch.inference_mode():
+        lg, v = net(torch.from_numpy(x))
+    assert np.abs(lg.numpy() - lg_ref).max() < 1e-5 * max(1.0, float(np.abs(lg_ref).max()))
+    assert np.abs(v.numpy() - v_ref).max() < 2e-5
 
 
 def test_flat_parameter_blob_length():
