@@ -28,6 +28,19 @@ class AzNetConfig(C.Structure):
                 ("value_hidden", C.c_int32), ("precision", C.c_int32), ("device", C.c_int32)]
 
 
+class AzLaneConfig(C.Structure):
+    _fields_ = [("temp_moves", C.c_int32), ("temp_mid_moves", C.c_int32), ("temp_start", C.c_double), ("temp_mid", C.c_double),
+                ("temp_end", C.c_double), ("resign_threshold", C.c_double), ("disable_resign", C.c_int32),
+                ("resign_min_move", C.c_int32), ("dirichlet_alpha", C.c_double), ("collect_samples", C.c_int32),
+                ("rng_threads", C.c_int32), ("use_graph", C.c_int32)]
+
+
+class AzLaneResult(C.Structure):
+    _fields_ = [("counters", C.c_int64 * 8), ("host_seconds_rng", C.c_double), ("n_over", C.c_int32), ("over_slot", C.c_void_p),
+                ("over_winner", C.c_void_p), ("bits", C.c_void_p), ("caps", C.c_void_p), ("pi32", C.c_void_p),
+                ("to_play", C.c_void_p), ("difficulty", C.c_void_p), ("actions", C.c_void_p), ("root_value", C.c_void_p)]
+
+
 # name -> (restype, argtypes); every symbol declared in include/azamd.h
 _VP, _I32, _I64 = C.c_void_p, C.c_int32, C.c_int64
 SIGNATURES = {
@@ -79,6 +92,12 @@ SIGNATURES = {
     "az_net_profile": (_I32, [_VP, _I32, C.POINTER(C.c_double), C.POINTER(_I64), C.POINTER(_I64)]),
     "az_replay_gather": (_I32, [_VP, _VP, _VP, _VP, _VP, _VP, _I32, _I32, _I32, _I32, _VP, _VP, _VP]),
     "az_pack_planes": (_I32, [_VP, _I32, _I32, _I32, _I32, _VP, _VP, _VP]),
+    "az_lane_create": (_I32, [_VP, _VP, _VP, C.POINTER(AzLaneConfig), _VP, _I32, _VP, _I32, _VP, _VP, C.POINTER(_VP)]),
+    "az_lane_destroy": (_I32, [_VP]),
+    "az_lane_slots": (_I32, [_VP, C.POINTER(_VP), C.POINTER(_VP)]),
+    "az_lane_prepare": (_I32, [_VP, _VP]),
+    "az_lane_launch": (_I32, [_VP, _I32, _VP]),
+    "az_lane_finish": (_I32, [_VP, C.POINTER(AzLaneResult)]),
     "az_rng_create": (_I32, [_I32, C.POINTER(_VP)]),
     "az_rng_destroy": (_I32, [_VP]),
     "az_rng_seed": (_I32, [_VP, _I32, C.c_uint32]),

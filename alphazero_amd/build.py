@@ -7,7 +7,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = ["az_engine.hip", "az_net.hip", "az_net_mfma.hip", "az_net_layers.hip", "az_replay.hip", "az_hostrng.cpp"]
-HDR = ["az_board.cuh", "az_net.h", "az_mfma_gemm.cuh", "../../include/azamd.h"]
+HDR = ["az_board.cuh", "az_net.h", "az_mfma_gemm.cuh", "az_lane.cuh", "../../include/azamd.h"]
 # -ffp-contract=off: the search kernels must round every float64 product and sum separately.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 

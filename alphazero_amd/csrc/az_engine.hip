@@ -76,6 +76,8 @@ struct Dev {
     uint8_t* root_cached;  // [G] root_logits holds the evaluation of the current root state
     uint8_t* tree_live;    // [G] the tree in memory was searched from the state before the next move
     long long* gstats; // [G][8] per-game counters of the current search (no cross-workgroup atomics on the hot kernels)
+    int* root_count;   // [G] legal actions (pass included) of each root whose row the last root-phase leaf gather wrote
+    int* ctl_mirror;   // null, or [4]: the root-phase row scan also leaves its counts here (a self-play lane's record)
 };
 
 __device__ inline int sc_idx(int g, int f) { return g * 8 + f; }
@@ -487,7 +489,10 @@ __global__ __launch_bounds__(1024) void k_scan_rows(Dev d, int root_phase) {
         }
         n_all = n_eval + n_late;
     }
-    if (t == 1023) { d.row_off[d.G] = n_all; d.ctl[0] = n_eval; d.ctl[2] = n_all; }
+    if (t == 1023) {
+        d.row_off[d.G] = n_all; d.ctl[0] = n_eval; d.ctl[2] = n_all;
+        if (root_phase && d.ctl_mirror) { d.ctl_mirror[0] = n_eval; d.ctl_mirror[2] = n_all; }
+    }
 }
 
 // (score, index) arg-max over the wave: largest score, smallest index among equals (idx must be unique per lane, or
@@ -746,8 +751,9 @@ __global__ __launch_bounds__(64) void k_leaf(Dev d, void* out, int layout) {
         }
     }
     const size_t row_bytes = layout == AZ_FEAT_F32_NCHW ? (size_t)d.C * d.np * 4 : (size_t)d.np * (d.C <= 32 ? 32 : 64) * 2;
-    emit_features<PPL>(d, lane, geo, b, seen_lds, hist_lds, BoardLds<PPL>::NPAD, hist_count, s,
-                       (unsigned char*)out + (size_t)r * row_bytes, layout, d.row_legal + (size_t)r * d.A);
+    const int n_legal = emit_features<PPL>(d, lane, geo, b, seen_lds, hist_lds, BoardLds<PPL>::NPAD, hist_count, s,
+                                           (unsigned char*)out + (size_t)r * row_bytes, layout, d.row_legal + (size_t)r * d.A);
+    if (slot < 0 && lane == 0) d.root_count[g] = n_legal;
 }
 
 // numpy pairwise summation of a contiguous float64 vector (ndarray.sum(), mcts.py:80), n <= 512, by the whole wave with
@@ -980,11 +986,19 @@ __device__ inline void expand_node(const Dev& d, int g, int lane, int node, cons
 }
 
 // Root expansion (mcts.py:172): one wave per game.
-__global__ __launch_bounds__(64) void k_expand_root(Dev d, const float* logits, const double* noise, double* priors_out) {
+// `enable` (may be null): games switched off after their root row was gathered leave the search here.
+__global__ __launch_bounds__(64) void k_expand_root(Dev d, const float* logits, const double* noise, double* priors_out, const uint8_t* enable) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
     double* p_lds = (double*)dyn;
     const int g = blockIdx.x, lane = threadIdx.x;
+    if (lane < 8) d.gstats[(size_t)g * 8 + lane] = 0;   // a search's counters start here (k_begin clears them too)
+    __syncthreads();
     if (!d.active[g]) return;
+    if (enable && !enable[g]) {
+        __syncthreads();
+        if (lane == 0) d.active[g] = 0;
+        return;
+    }
     const int r = d.row_off[g];
     const float* lg = (d.rc_cap && d.root_cached[g]) ? d.root_logits + (size_t)g * d.A : logits + (size_t)r * d.A;
     expand_node(d, g, lane, 0, lg, d.row_legal + (size_t)r * d.A,
@@ -1158,6 +1172,7 @@ struct az_engine {
     int* ctl_host = nullptr;        // pinned
     long long* stats_host = nullptr;
     double* last_priors = nullptr;  // [max_rows][A]
+    const uint8_t* root_enable = nullptr;   // device mask a self-play lane hands to the root expansion (null: every active game)
     std::vector<void*> allocs;
     // az_mcts_run_rounds: the launches of all remaining batch rounds of a search, captured once and replayed per move
     hipGraphExec_t rounds_exec = nullptr;
@@ -1229,6 +1244,7 @@ int az_engine_create(const az_config* c, az_engine** out) {
     ALLOC(term_value, (size_t)d.G * d.B); ALLOC(n_unique, d.G); ALLOC(uniq_slot, (size_t)d.G * d.B);
     ALLOC(row_off, d.G + 1); ALLOC(row_game, d.max_rows); ALLOC(row_slot, d.max_rows);
     ALLOC(row_legal, (size_t)d.max_rows * d.A); ALLOC(ctl, 4); ALLOC(stats, 8); ALLOC(gstats, (size_t)d.G * 8);
+    ALLOC(root_count, d.G);
     {
         int rc = dev_alloc(e, &e->last_priors, (size_t)d.max_rows * d.A);
         if (rc != AZ_OK) { az_engine_destroy(e); return rc; }
@@ -1465,7 +1481,7 @@ int az_mcts_expand(az_engine* e, const float* logits, const float* values, const
     const size_t shmem = (size_t)e->d.A * 16 + (size_t)e->d.B * 16 + 64;
     if (e->phase == PH_ROOT) {
         if (!logits && !(e->d.rc_cap && e->rows_known && e->pending_rows == 0)) return fail(AZ_ERR_ARG, "null logits");
-        hipLaunchKernelGGL(k_expand_root, dim3(e->d.G), dim3(64), shmem, (hipStream_t)stream, e->d, logits, noise, e->last_priors);
+        hipLaunchKernelGGL(k_expand_root, dim3(e->d.G), dim3(64), shmem, (hipStream_t)stream, e->d, logits, noise, e->last_priors, e->root_enable);
     } else if (e->phase == PH_SELECTED) {
         if (!e->async_mode) {
             int rc = need_rows(e, stream);
@@ -1592,3 +1608,5 @@ int az_mcts_stats(az_engine* e, int64_t* out, void* stream) {
 }
 
 }  // extern "C"
+
+#include "az_lane.cuh"

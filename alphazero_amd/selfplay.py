@@ -22,6 +22,9 @@ from . import _native as N
 from .engine import GRAPH_ROUNDS, Engine
 
 NATIVE_ROUNDS = os.environ.get("AZ_NATIVE_ROUNDS", "1") != "0"   # 0: one call per kernel from Python (A/B timing)
+# 0: the per-move host half (policy targets, move sampling, resignation, play, status) in NumPy with a device round trip per
+# piece, as before the native lane (az_lane_*) existed; same games either way (A/B timing and cross-check)
+NATIVE_LANE = os.environ.get("AZ_NATIVE_LANE", "1") != "0"
 
 
 @dataclass
@@ -198,12 +201,65 @@ class _Lane:
             self.info_np = None
             self.step_no = 0
         self.inflight = None
+        self.nl = None               # native lane (az_lane_*): created at begin() when the search runs without round trips
+        self.native = False
+        self.move_idx = np.zeros(self.G, np.int64)
+
+    def __del__(self):
+        self._drop_native()
+
+    def _drop_native(self):
+        if getattr(self, "nl", None):
+            N.lib().az_lane_destroy(self.nl)
+            self.nl = None
+        self.native = False
+
+    def _make_native(self):
+        """The native lane: one enqueue and one device-to-host copy per move (az_lane_*)."""
+        cfg, L = self.o.cfg, N.lib()
+        # visits ** (1 / T) for every possible visit count, from NumPy's own pow: the bits upstream's np.power gives on
+        # this host (mcts.py:274), whatever libm or the device would return
+        plen = cfg.mcts_simulations + 2
+        v = np.arange(plen, dtype=np.float64)
+        tabs = np.zeros((3, plen), np.float64)
+        for i, t in enumerate((cfg.temp_start, cfg.temp_mid, cfg.temp_end)):
+            if t > 1e-2:
+                tabs[i] = np.power(v, 1.0 / t)
+        lc = N.AzLaneConfig(int(cfg.temp_moves), int(cfg.temp_mid_moves), float(cfg.temp_start), float(cfg.temp_mid), float(cfg.temp_end),
+                            float(cfg.resign_threshold), 1 if cfg.disable_resign else 0, 12, float(cfg.dirichlet_alpha),
+                            1 if self.o.collect else 0, int(self.rng.threads), 1 if self.o.graph_rounds else 0)
+        h = C.c_void_p()
+        with torch.cuda.device(self.dev):
+            N.check(L.az_lane_create(self.eng._h, self.net._h, self.rng._h, C.byref(lc), tabs.ctypes.data_as(C.c_void_p), plen,
+                                     C.c_void_p(self.feat_buf.data_ptr()), int(self.layout), C.c_void_p(self.logits_buf.data_ptr()),
+                                     C.c_void_p(self.values_buf.data_ptr()), C.byref(h)), "az_lane_create")
+        self.nl = h
+        p_on, p_mi = C.c_void_p(), C.c_void_p()
+        N.check(L.az_lane_slots(h, C.byref(p_on), C.byref(p_mi)), "az_lane_slots")
+        self.slot_on = np.ctypeslib.as_array(C.cast(p_on, C.POINTER(C.c_uint8)), shape=(self.G,))
+        self.nl_move_idx = np.ctypeslib.as_array(C.cast(p_mi, C.POINTER(C.c_int32)), shape=(self.G,))
+        n, H = cfg.board_size, cfg.history_len
+        self.row_bytes = ((2 * H + 3) * n * n + 7) // 8
+        self.over_slot = np.zeros(self.G, np.int32)
+        self.over_winner = np.zeros(self.G, np.int32)
+        self.actions_np = np.zeros(self.G, np.int32)
+        self.rv_np = np.zeros(self.G, np.float64)
+
+    def _stream_ptr(self):
+        return C.c_void_p(self.stream.cuda_stream)
 
     # ------------------------------------------------------------------ slots
     def begin(self):
         G = self.G
         self.game_id = np.full(G, -1, np.int64)
-        self.move_idx = np.zeros(G, np.int64)
+        want_native = NATIVE_LANE and self.async_search and self.net is not None
+        if want_native and self.nl is None:
+            self._make_native()
+        elif not want_native:
+            self._drop_native()
+        self.native = want_native
+        self.move_idx = self.nl_move_idx if self.native else np.zeros(G, np.int64)
+        self.move_idx[:] = 0
         with torch.cuda.stream(self.stream):
             self.eng.reset()
         for s in range(G):
@@ -218,6 +274,10 @@ class _Lane:
         self.inflight = None
         self.info_np = None
         self._open_games(np.nonzero(self.game_id >= 0)[0])
+        if self.native:
+            self.slot_on[:] = self.game_id >= 0
+            with torch.cuda.stream(self.stream):
+                N.check(N.lib().az_lane_prepare(self.nl, self._stream_ptr()), "az_lane_prepare")
 
     def _open_games(self, slots):
         """Opening-book moves of the games just dealt to `slots` (train.py:291-311). A game's book draws come
@@ -252,6 +312,13 @@ class _Lane:
     def launch(self):
         active = self.game_id >= 0
         if not active.any():
+            return
+        if self.native:      # the whole move in one native call: random draws, one upload, every kernel, one download
+            refill = 1 if self.o.next_id < self.o.num_games else 0
+            with torch.cuda.stream(self.stream):
+                if N.check(N.lib().az_lane_launch(self.nl, refill, self._stream_ptr()), "az_lane_launch") == 1:
+                    self.o.counters["graph_replays"] += 1
+            self.inflight = (active,)
             return
         eng, c, cfg = self.eng, self.o.counters, self.o.cfg
         with torch.cuda.stream(self.stream):
@@ -307,9 +374,51 @@ class _Lane:
         self.inflight = (active, to_play, packed, visits, rv)
 
     # ------------------------------------------------------------------ one move, second half (train.py:322-343)
+    def _finish_native(self):
+        o, G, A, c = self.o, self.G, self.A, self.o.counters
+        t0 = time.perf_counter()
+        r = N.AzLaneResult()
+        r.over_slot, r.over_winner = self.over_slot.ctypes.data, self.over_winner.ctypes.data
+        r.actions, r.root_value = self.actions_np.ctypes.data, self.rv_np.ctypes.data
+        if o.collect:
+            bits, caps = np.empty((G, self.row_bytes), np.uint8), np.empty((G, 2), np.float32)
+            pi32, to_play, diff = np.empty((G, A), np.float32), np.empty(G, np.int32), np.empty(G, np.float64)
+            r.bits, r.caps, r.pi32, r.to_play, r.difficulty = bits.ctypes.data, caps.ctypes.data, pi32.ctypes.data, to_play.ctypes.data, diff.ctypes.data
+        N.check(N.lib().az_lane_finish(self.nl, C.byref(r)), "az_lane_finish")
+        if o.collect:
+            self.log.append((bits, caps, pi32, to_play, diff))
+        k = r.counters
+        c["sims"] += k[0]; c["nn_rows"] += k[1]; c["nn_rows_nodedup"] += k[2]; c["depth_sum"] += k[3]; c["moves"] += k[7]
+        c["t_host_rng"] += r.host_seconds_rng
+        if r.n_over:
+            fresh = []
+            for s, winner in zip(self.over_slot[: r.n_over].tolist(), self.over_winner[: r.n_over].tolist()):
+                o.results[0 if winner == 1 else (1 if winner == -1 else 2)] += 1
+                o.finished[int(self.game_id[s])] = (self.index, s, int(self.start_step[s]), self.step_no + 1, winner)
+                self.start_step[s] = self.step_no + 1
+                c["games"] += 1
+                gid = o._deal()
+                self.game_id[s] = gid
+                if gid >= 0:
+                    self.rng.seed(s, o.seed0 + gid)
+                    fresh.append(s)
+                else:
+                    self.slot_on[s] = 0
+            cfg = o.cfg
+            if fresh and cfg.opening_book_prob > 0.0 and cfg.opening_book_max_moves > 0:
+                # book moves are played from the host: the roots the move's tail prepared for these slots are stale
+                with torch.cuda.stream(self.stream):
+                    self._open_games(np.array(fresh))
+                    N.check(N.lib().az_lane_prepare(self.nl, self._stream_ptr()), "az_lane_prepare")
+        c["t_host_policy"] += time.perf_counter() - t0
+        self.step_no += 1
+
     def finish(self):
         if self.inflight is None:
             return
+        if self.native:
+            self.inflight = None
+            return self._finish_native()
         active, to_play, packed, visits, rv = self.inflight
         self.inflight = None
         o, cfg, G, eng, A = self.o, self.o.cfg, self.G, self.eng, self.A

@@ -248,6 +248,64 @@ int az_rng_dirichlet(az_rng* r, const int32_t* counts_host, double alpha, double
 /* One uniform double in [0,1) per stream with mask_host[g] != 0 (NULL = all): RandomState.random_sample(). */
 int az_rng_random_sample(az_rng* r, const uint8_t* mask_host, double* out_host);
 
+/* ---- self-play lane: a whole move of every lockstep game per enqueue ----------------------------
+ * Takes over, for the G games of an engine, one iteration of the loop of selfplay_game (go_zero/train.py:322-343)
+ * around MCTS.run (mcts.py:227-284): root noise, search, visits -> policy target with the move's temperature
+ * (mcts.py:270-279), the sampled action (mcts.py:281), difficulty (train.py:336-337), resignation (train.py:339-341),
+ * the training sample's planes (go.py:265-304), GoState.play (train.py:342) and the terminal test / winner
+ * (train.py:322, :345). Everything but the random draws runs on the device; the host waits once per move.
+ * The engine must be in asynchronous mode and `net` a bf16 network with az_net_reserve(az_engine_max_rows) done. */
+typedef struct az_lane az_lane;
+typedef struct {
+    int32_t temp_moves, temp_mid_moves;       /* train.py:323-328: move index below which temp_start / temp_mid apply */
+    double temp_start, temp_mid, temp_end;
+    double resign_threshold;                  /* train.py:339 */
+    int32_t disable_resign, resign_min_move;  /* upstream resigns from move index 12 on */
+    double dirichlet_alpha;                   /* mcts.py:122 */
+    int32_t collect_samples;                  /* keep (planes, pi, to_play, difficulty) of every searched position */
+    int32_t rng_threads;                      /* host threads drawing the Dirichlet samples */
+    int32_t use_graph;                        /* replay the batch rounds from a HIP graph where the network allows it */
+} az_lane_config;
+/* What az_lane_finish reports. Array pointers are host memory owned by the caller, G entries (rows) each, NULL to skip. */
+typedef struct {
+    int64_t counters[8];   /* out: simulations, rows evaluated (root rows included), rows before dedup, sum of leaf depths,
+                              max depth, max nodes, terminal leaves, positions searched */
+    double host_seconds_rng; /* out: host time spent drawing this move's random numbers */
+    int32_t n_over;        /* out: games that ended with this move (resignation, two passes, move cap) */
+    int32_t* over_slot;    /* out [n_over]: their slots, ascending; the slot already holds a fresh game */
+    int32_t* over_winner;  /* out [n_over]: +1 black, -1 white, 0 draw (train.py:345) */
+    uint8_t* bits;         /* out [G][row_bytes], row_bytes = ceil((2H+3)*n*n / 8): binary planes of the searched state,
+                              numpy.packbits order (collect_samples) */
+    float* caps;           /* out [G][2]: values of the two capture planes (collect_samples) */
+    float* pi32;           /* out [G][A]: policy target (collect_samples) */
+    int32_t* to_play;      /* out [G]: side to move in the searched state */
+    double* difficulty;    /* out [G]: max(0.01, 1 - max pi) */
+    int32_t* actions;      /* out [G]: the sampled action (-1: empty slot) */
+    double* root_value;    /* out [G] */
+} az_lane_result;
+/* pow_tables_host: double [3][pow_len], pow_len > simulations: v ** (1 / T) for v = 0..pow_len-1 and T = temp_start,
+ * temp_mid, temp_end, computed by the caller with the pow whose bits it wants (upstream: numpy.power, mcts.py:274).
+ * feat_dev / logits_dev / values_dev: device buffers for az_engine_max_rows rows, as for az_mcts_run_rounds. `rng`: one
+ * stream per slot; the caller seeds a slot's stream when it deals a game to it. */
+int az_lane_create(az_engine* e, az_net* net, az_rng* rng, const az_lane_config* cfg, const double* pow_tables_host,
+                   int32_t pow_len, void* feat_dev, int32_t layout, float* logits_dev, float* values_dev, az_lane** out);
+int az_lane_destroy(az_lane* lane);
+/* Host arrays the caller edits between moves: slot_on uint8 [G] (1: the slot holds a running game), move_idx int32 [G]
+ * (moves played so far in the slot's game; az_lane_finish advances it and zeroes it when a game ends). */
+int az_lane_slots(az_lane* lane, uint8_t** slot_on_host, int32_t** move_idx_host);
+/* Evaluate the roots of the current states (az_mcts_begin + root rows through the network) without waiting: after
+ * az_rules_reset / az_rules_play from outside the lane (new lane, opening-book moves) and before az_lane_launch. */
+int az_lane_prepare(az_lane* lane, void* stream);
+/* Enqueue one move of every running game: draws each game's Dirichlet sample and move-choice uniform from its stream,
+ * then root expansion, all batch rounds, the move itself and the evaluation of the next roots. refill != 0: a slot whose
+ * game ends with this move starts a fresh game at once (the caller deals it an id after az_lane_finish, or clears its
+ * slot_on flag); refill == 0: such a slot goes idle. Returns 1 when the rounds were replayed from a graph, 0 otherwise,
+ * < 0 on error. */
+int az_lane_launch(az_lane* lane, int32_t refill, void* stream);
+/* Wait for the move enqueued by az_lane_launch and report it. Failures of the search (AZ_ERR_NOCHILD, AZ_ERR_CAPACITY) and
+ * an illegal sampled move (AZ_ERR_ILLEGAL, "Illegal move: (r, c)") surface here. */
+int az_lane_finish(az_lane* lane, az_lane_result* result);
+
 /* ---- replay batch assembly (go_zero/train.py:147-176 ReplayBuffer.sample, :187-207 symmetries) ----
  * Gathers `count` sampled positions idx[i] from a device-resident replay store and applies dihedral
  * symmetry sym[i] (0..7, the numbering of train.py:187-192) to planes and policy. Store layout: `bits`
