@@ -62,10 +62,12 @@ struct Dev {
     double* term_value;  // [G][B]
     int* n_unique;    // [G]
     int* uniq_slot;   // [G][B]
+    int* brec;        // [G][4 + 4 B] batch record of a game's descents (select_body)
     int* row_off;     // [G+1]
     int* row_game; int* row_slot;  // [max_rows]
     uint8_t* row_legal;  // [max_rows][A]
-    int* ctl;         // [4] rows to evaluate, error code, rows to gather (>= rows to evaluate: roots with carried-over logits come last), -
+    int* ctl;         // [8] rows to evaluate, error code, rows to gather (>= rows to evaluate: roots with carried-over logits come last), -,
+                      //     [4], [5]: row counters of the even / odd batch rounds of az_mcts_run_rounds
     long long* stats; // [8], filled by k_reduce_stats
     // Root-evaluation reuse (rc_cap > 0): the root of the next search is the child played after this one, and that child was
     // evaluated as a leaf of this search; its logits are kept so that a batch-invariant evaluator need not see it again.
@@ -535,11 +537,70 @@ __device__ inline void wave_argmax(double& s, int& idx) {
     s = m; idx = __builtin_amdgcn_readlane(cand, 63);
 }
 
-// mcts.py:181-199: batch_n descents for game blockIdx.x.
+// Actions (and root children) per lane in the search kernels of a board class: boards up to 11x11 have at most 122 actions
+// (2 per lane), 12x12 and 13x13 at most 170 (3), boards up to 19x19 at most 362 (6).
+template <int PPL> struct Apl { static constexpr int v = PPL <= 2 ? 2 : PPL; };
+
+// The root's and its children's statistics in the wave's registers for a whole batch (child i: lane i & 63, slot i >> 6):
+// every descent starts at the root and, with virtual loss, most end at one of its children.
+template <int CPL>
+struct RootCache {
+    int rnc, rfirst, r_vis;
+    double r_vsum;
+    double prior[CPL], vsum[CPL];
+    int vis[CPL], nch[CPL], act[CPL];
+    __device__ bool held() const { return rnc > 0 && rnc <= 64 * CPL; }
+};
+
+template <int CPL>
+__device__ inline void rc_load(const Dev& d, size_t nb, int lane, int rnc, int rfirst, RootCache<CPL>& c) {
+    c.rnc = rnc; c.rfirst = rfirst;
+    c.r_vis = d.visits[nb]; c.r_vsum = d.vsum[nb];
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+        const int i = lane + 64 * k;
+        c.prior[k] = 0.0; c.vsum[k] = 0.0; c.vis[k] = 0; c.nch[k] = 0; c.act[k] = 0;
+        if (c.held() && i < rnc) {
+            const size_t x = nb + rfirst + i;
+            c.prior[k] = d.prior[x]; c.vsum[k] = d.vsum[x]; c.vis[k] = d.visits[x]; c.nch[k] = d.n_child[x]; c.act[k] = d.action[x];
+        }
+    }
+}
+
+template <int CPL>
+__device__ inline void rc_store(const Dev& d, size_t nb, int lane, const RootCache<CPL>& c) {
+    if (!c.held()) return;
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+        const int i = lane + 64 * k;
+        if (i < c.rnc) { d.visits[nb + c.rfirst + i] = c.vis[k]; d.vsum[nb + c.rfirst + i] = c.vsum[k]; }
+    }
+    if (lane == 0) { d.visits[nb] = c.r_vis; d.vsum[nb] = c.r_vsum; }
+}
+
+// arr[idx >> 6] of lane idx & 63; idx must be wave-uniform
+template <int CPL>
+__device__ inline int rc_read(const int (&arr)[CPL], int idx) {
+    int v = 0;
+#pragma unroll
+    for (int k = 0; k < CPL; ++k)
+        if (k == (idx >> 6)) v = __builtin_amdgcn_readlane(arr[k], idx & 63);
+    return v;
+}
+
+// The batch record a game's descents leave for the expansion that follows the network (int32 [4 + 4 B] per game, read
+// back with one load per lane): [0] distinct leaves, [1] -, [2] children of the root, [3] index of its first child, then
+// per slot s: path length | (slot whose row evaluates the leaf + 1) << 16 (0: terminal), the root child on the path (-1:
+// the path ends at the root), the leaf node; then the slots of the distinct leaves in row order.
+__device__ inline int brec_words(const Dev& d) { return 4 + 4 * d.B; }
+
+// mcts.py:181-199: batch_n descents for game blockIdx.x. `rc` holds the root's statistics (rc_load) and is left updated,
+// not stored. rows_ctr: null (the row scan kernel assigns the rows), or the counter this batch's rows are allotted from.
 template <int PPL>
-__device__ __forceinline__ void select_body(const Dev& d, int batch_n) {
+__device__ __forceinline__ void select_body(const Dev& d, int batch_n, RootCache<Apl<PPL>::v>& rc, int root_passes, int root_moves,
+                                            double t_pbc, double t_sqn, int t_base, int* rows_ctr) {
+    constexpr int CPL = Apl<PPL>::v;
     __shared__ BoardLds<PPL> b;
-    __shared__ int8_t root_col[BoardLds<PPL>::NPAD];
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
     uint64_t* seen_lds = (uint64_t*)dyn;
     double* tc_val = (double*)(seen_lds + d.seen_cap);   // outcomes of the terminal leaves met in this batch ...
@@ -550,19 +611,12 @@ __device__ __forceinline__ void select_body(const Dev& d, int batch_n) {
     constexpr int PSTAGE = 8;                        // path nodes staged per descent; a longer path is written at once
     int* st_len = uniq_lds + 2 * d.B;                // [B]
     int* st_ref = st_len + d.B;                      // [B]
-    int* st_path = st_ref + d.B;                     // [B][PSTAGE]
+    int* st_n1 = st_ref + d.B;                       // [B] the root child on the path
+    int* st_leaf = st_n1 + d.B;                      // [B] the leaf node
+    int* st_path = st_leaf + d.B;                    // [B][PSTAGE]
     int* tc_node = st_path + d.B * PSTAGE;           // ... and their nodes: with virtual loss the descents of a batch mostly end
     int n_tc = 0;                                    // in the same leaf, and a terminal one is replayed and scored once
     const int g = blockIdx.x, lane = threadIdx.x;
-    if (!d.active[g]) { if (lane == 0) d.n_unique[g] = 0; return; }
-    Geo<PPL> geo;
-    geo_init<PPL>(geo, d.n, lane);
-    Sim<PPL> root;
-    sim_load_root<PPL>(d, g, lane, geo, b, seen_lds, root);
-#pragma unroll
-    for (int k = 0; k < PPL; ++k)
-        if (geo.p[k] >= 0) root_col[geo.p[k]] = b.col[geo.p[k]];
-    __syncthreads();
 
     const size_t nb = (size_t)g * d.max_nodes;
     double* prior = d.prior + nb; double* vsum = d.vsum + nb; int* visits = d.visits + nb;
@@ -570,27 +624,23 @@ __device__ __forceinline__ void select_body(const Dev& d, int batch_n) {
     int n_unique = 0, depth_sum = 0, max_depth = 0, n_term = 0;
 
     // The descent itself needs no board: children only exist for legal moves, and whether a node is terminal
-    // follows from the pass count and the move count (go.py:205-206). The moves are replayed on the LDS board
+    // follows from the pass count and the move count (go.py:205-206). The moves are replayed on an LDS board
     // only for a terminal leaf, whose outcome needs the final position (the leaf gather replays the others).
-    // The statistics of the root and of its children (lane i: child i, when there are at most 64) live in
-    // registers for the whole batch: every descent starts there, and with virtual loss most end there.
-    const int rnc = n_child[0], rfirst = child_off[0];
-    const bool cached = rnc > 0 && rnc <= 64;
-    double c_prior = 0.0, c_vsum = 0.0, r_vsum = vsum[0];
-    int c_vis = 0, c_nch = 0, c_act = 0, r_vis = visits[0];
-    if (cached && lane < rnc) {
-        c_prior = prior[rfirst + lane]; c_vsum = vsum[rfirst + lane]; c_vis = visits[rfirst + lane];
-        c_nch = n_child[rfirst + lane]; c_act = action[rfirst + lane];
-    }
+    const int rnc = rc.rnc, rfirst = rc.rfirst;
+    const bool cached = rc.held();
     // the root's visit count during descent `slot` is r_vis + slot with virtual loss (else r_vis): lane i holds the
-    // exploration-table entries of r_vis + i, so the descents from the root start without a dependent table load
-    const int t_idx = min(r_vis + (d.vl > 0.0 ? lane : 0), d.tab_len - 1);
-    const double t_pbc = d.pbc[t_idx], t_sqn = d.sqn[t_idx];
+    // exploration-table entries of t_base + i, fetched before the root's statistics were known; t_base is the visit count
+    // the caller expects (the simulations finished so far)
+    if (rc.r_vis != t_base) {
+        const int t_idx = min(rc.r_vis + (d.vl > 0.0 ? lane : 0), d.tab_len - 1);
+        t_pbc = d.pbc[t_idx]; t_sqn = d.sqn[t_idx];
+    }
+    const int r_vis0 = rc.r_vis;
     for (int slot = 0; slot < batch_n; ++slot) {
         int* path = d.path + ((size_t)g * d.B + slot) * d.max_depth;
         int node = 0, len = 1, nc = rnc;
         int child_vis = -1;   // visit count of the current node when it is a root child held in registers
-        int passes = root.passes, moves = root.moves;
+        int passes = root_passes, moves = root_moves;
         if (lane == 0) path_lds[0] = 0;
         bool failed = false;
         while (true) {
@@ -599,33 +649,49 @@ __device__ __forceinline__ void select_body(const Dev& d, int batch_n) {
             const bool at_root = cached && node == 0;
             const int first = at_root ? rfirst : child_off[node];
             double pbc, sq;
-            if (at_root && slot < 64) {   // slot is wave-uniform: register reads, no lane shuffle
-                pbc = readlane_f64(t_pbc, slot); sq = readlane_f64(t_sqn, slot);
+            const int tslot = d.vl > 0.0 ? rc.r_vis - r_vis0 : 0;   // = slot with virtual loss
+            if (at_root && tslot < 64) {   // wave-uniform: register reads, no lane shuffle
+                pbc = readlane_f64(t_pbc, tslot); sq = readlane_f64(t_sqn, tslot);
             } else {
-                int pv = at_root ? r_vis : (child_vis >= 0 ? child_vis : visits[node]);
+                int pv = at_root ? rc.r_vis : (child_vis >= 0 ? child_vis : visits[node]);
                 pv = pv < d.tab_len ? pv : d.tab_len - 1;
                 pbc = d.pbc[pv]; sq = d.sqn[pv];
             }
             double best = -INFINITY;
             int best_i = 0x7fffffff;
-            for (int i0 = 0; i0 < nc; i0 += 64) {
-                const int i = i0 + lane;
-                if (i < nc) {
-                    const int vc = at_root ? c_vis : visits[first + i];
-                    double pb = pbc * (sq / ((double)vc + 1.0));
-                    const double prior_score = pb * (at_root ? c_prior : prior[first + i]);
-                    const double value_score = -(vc == 0 ? 0.0 : (at_root ? c_vsum : vsum[first + i]) / (double)vc);
-                    const double score = prior_score + value_score;
-                    if (score > -1e18 && (score > best)) { best = score; best_i = i; }
+            if (at_root) {
+#pragma unroll
+                for (int k = 0; k < CPL; ++k) {
+                    const int i = lane + 64 * k;
+                    if (i < nc) {
+                        const int vc = rc.vis[k];
+                        double pb = pbc * (sq / ((double)vc + 1.0));
+                        const double prior_score = pb * rc.prior[k];
+                        const double value_score = -(vc == 0 ? 0.0 : rc.vsum[k] / (double)vc);
+                        const double score = prior_score + value_score;
+                        if (score > -1e18 && (score > best)) { best = score; best_i = i; }
+                    }
+                }
+            } else {
+                for (int i0 = 0; i0 < nc; i0 += 64) {
+                    const int i = i0 + lane;
+                    if (i < nc) {
+                        const int vc = visits[first + i];
+                        double pb = pbc * (sq / ((double)vc + 1.0));
+                        const double prior_score = pb * prior[first + i];
+                        const double value_score = -(vc == 0 ? 0.0 : vsum[first + i] / (double)vc);
+                        const double score = prior_score + value_score;
+                        if (score > -1e18 && (score > best)) { best = score; best_i = i; }
+                    }
                 }
             }
             wave_argmax(best, best_i);
             if (best_i == 0x7fffffff) { failed = true; break; }  // mcts.py:114-115
             node = first + best_i;
             // best_i is wave-uniform (wave_argmax returns it from one lane)
-            const int act = at_root ? __builtin_amdgcn_readlane(c_act, best_i) : (int)action[node];
-            nc = at_root ? __builtin_amdgcn_readlane(c_nch, best_i) : (int)n_child[node];
-            child_vis = at_root ? __builtin_amdgcn_readlane(c_vis, best_i) : -1;
+            const int act = at_root ? rc_read<CPL>(rc.act, best_i) : (int)action[node];
+            nc = at_root ? rc_read<CPL>(rc.nch, best_i) : (int)n_child[node];
+            child_vis = at_root ? rc_read<CPL>(rc.vis, best_i) : -1;
             passes = act == d.np ? passes + 1 : 0;
             moves += 1;
             if (lane == 0) path_lds[len] = node;
@@ -646,11 +712,11 @@ __device__ __forceinline__ void select_body(const Dev& d, int batch_n) {
             if (hit >= 0) {
                 v = tc_val[hit];
             } else {
-                Sim<PPL> s = root;
-#pragma unroll
-                for (int k = 0; k < PPL; ++k)
-                    if (geo.p[k] >= 0) b.col[geo.p[k]] = root_col[geo.p[k]];
+                Geo<PPL> geo;
+                geo_init<PPL>(geo, d.n, lane);
+                Sim<PPL> s;
                 __syncthreads();
+                sim_load_root<PPL>(d, g, lane, geo, b, seen_lds, s);
                 for (int i = 1; i < len; ++i) sim_play<PPL>(d, lane, geo, b, seen_lds, nullptr, s, (int)action[path_lds[i]]);
                 v = sim_outcome<PPL>(d, geo, b, s);
                 if (lane == 0) { tc_node[n_tc] = node; tc_val[n_tc] = v; }
@@ -673,15 +739,20 @@ __device__ __forceinline__ void select_body(const Dev& d, int batch_n) {
                 n_unique += 1;
             }
         }
-        if (lane == 0) { st_len[slot] = len; st_ref[slot] = ref; }
+        if (lane == 0) { st_len[slot] = len; st_ref[slot] = ref; st_n1[slot] = len > 1 ? path_lds[1] : -1; st_leaf[slot] = node; }
         depth_sum += len - 1;
         max_depth = max(max_depth, len - 1);
         wave_sync();
         if (d.vl > 0.0) {  // mcts.py:196-199
             if (cached) {
-                r_vis += 1;
-                r_vsum -= d.vl;
-                if (len > 1 && lane == path_lds[1] - rfirst) { c_vis += 1; c_vsum -= d.vl; }
+                rc.r_vis += 1;
+                rc.r_vsum -= d.vl;
+                if (len > 1) {
+                    const int ci = path_lds[1] - rfirst;
+#pragma unroll
+                    for (int k = 0; k < CPL; ++k)
+                        if (lane + 64 * k == ci) { rc.vis[k] += 1; rc.vsum[k] -= d.vl; }
+                }
             }
             for (int i = (cached ? 2 : 0) + lane; i < len; i += 64) {
                 const int pn = path_lds[i];
@@ -691,21 +762,30 @@ __device__ __forceinline__ void select_body(const Dev& d, int batch_n) {
         }
         wave_sync();
     }
-    if (cached) {
-        if (lane < rnc) { visits[rfirst + lane] = c_vis; vsum[rfirst + lane] = c_vsum; }
-        if (lane == 0) { visits[0] = r_vis; vsum[0] = r_vsum; }
-    }
+    // the batch's results: the record for the expansion, the path lengths and slot tables the leaf gather reads
+    int* brec = d.brec + (size_t)g * brec_words(d);
     for (int sl = lane; sl < batch_n; sl += 64) {
         const int len = st_len[sl];
         d.path_len[g * d.B + sl] = len;
         d.leaf_ref[g * d.B + sl] = st_ref[sl];
+        brec[4 + sl] = len | ((st_ref[sl] + 1) << 16);
+        brec[4 + d.B + sl] = st_n1[sl];
+        brec[4 + 2 * d.B + sl] = st_leaf[sl];
         if (len <= PSTAGE) {
             int* path = d.path + ((size_t)g * d.B + sl) * d.max_depth;
             for (int i = 0; i < len; ++i) path[i] = st_path[sl * PSTAGE + i];
         }
     }
-    for (int u = lane; u < n_unique; u += 64) d.uniq_slot[g * d.B + u] = uniq_lds[2 * u];
+    for (int u = lane; u < n_unique; u += 64) { d.uniq_slot[g * d.B + u] = uniq_lds[2 * u]; brec[4 + 3 * d.B + u] = uniq_lds[2 * u]; }
+    int row0 = 0;
+    if (rows_ctr) {   // this game's rows: allotted from the batch's counter (their order among the games does not matter)
+        if (lane == 0 && n_unique > 0) row0 = atomicAdd(rows_ctr, n_unique);
+        row0 = __builtin_amdgcn_readfirstlane(row0);
+        for (int u = lane; u < n_unique; u += 64) { d.row_game[row0 + u] = g; d.row_slot[row0 + u] = uniq_lds[2 * u]; }
+    }
     if (lane == 0) {
+        brec[0] = n_unique; brec[1] = 0; brec[2] = rnc; brec[3] = rfirst;
+        if (rows_ctr) d.row_off[g] = row0;
         d.n_unique[g] = n_unique;
         long long* gs = d.gstats + (size_t)g * 8;
         gs[ST_DEPTH_SUM] += depth_sum;
@@ -717,19 +797,33 @@ __device__ __forceinline__ void select_body(const Dev& d, int batch_n) {
     }
 }
 
+// The first batch of a search (the later ones run behind the previous batch's expansion in k_expand_select).
 template <int PPL>
-__global__ __launch_bounds__(64) void k_select(Dev d, int batch_n) { select_body<PPL>(d, batch_n); }
+__global__ __launch_bounds__(64) void k_select(Dev d, int batch_n, int* rows_ctr, int visits_hint) {
+    const int g = blockIdx.x, lane = threadIdx.x;
+    if (!d.active[g]) { if (lane == 0) { d.n_unique[g] = 0; d.brec[(size_t)g * brec_words(d)] = 0; } return; }
+    const int t_idx = min(visits_hint + (d.vl > 0.0 ? lane : 0), d.tab_len - 1);
+    const double t_pbc = d.pbc[t_idx], t_sqn = d.sqn[t_idx];
+    const int passes = d.sc[sc_idx(g, SC_PASSES)], moves = d.sc[sc_idx(g, SC_MOVES)];
+    const size_t nb = (size_t)g * d.max_nodes;
+    RootCache<Apl<PPL>::v> rc;
+    rc_load<Apl<PPL>::v>(d, nb, lane, d.n_child[nb], d.child_off[nb], rc);
+    select_body<PPL>(d, batch_n, rc, passes, moves, t_pbc, t_sqn, visits_hint, rows_ctr);
+    rc_store<Apl<PPL>::v>(d, nb, lane, rc);
+}
 
 // Leaf gather: one wave per pending row replays the row's path from its game's root and writes the
 // feature planes (dense, row order) and the legal mask.
+// n_rows: the device-side row count; zero_ctr (may be null): a counter block 0 clears for the batch after next.
 template <int PPL>
-__global__ __launch_bounds__(64) void k_leaf(Dev d, void* out, int layout) {
+__global__ __launch_bounds__(64) void k_leaf(Dev d, void* out, int layout, const int* n_rows, int* zero_ctr) {
     __shared__ BoardLds<PPL> b;
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
     uint64_t* seen_lds = (uint64_t*)dyn;
     int8_t* hist_lds = (int8_t*)(dyn + (size_t)d.seen_cap * 8);
     const int r = blockIdx.x, lane = threadIdx.x;
-    if (r >= d.ctl[2]) return;
+    if (zero_ctr && r == 0 && lane == 0) *zero_ctr = 0;
+    if (r >= *n_rows) return;
     const int g = d.row_game[r], slot = d.row_slot[r];
     Geo<PPL> geo;
     geo_init<PPL>(geo, d.n, lane);
@@ -812,11 +906,12 @@ __device__ inline double pw_sum_wave(const double* a, int n, int lane) {
 }
 
 // mcts.py:66-91 + :118-137 for one node: masked softmax (float64), optional noise, top-k, children.
-// p_lds: double[2*A] work arrays (probabilities, ranking keys); runs on the whole wave.
-__device__ inline void expand_node(const Dev& d, int g, int lane, int node, const float* logits, const uint8_t* legal,
-                                   const double* noise, double* p_lds, double* priors_out) {
+// p_lds: double[2*A] work arrays (probabilities, ranking keys); runs on the whole wave. PPA: actions per lane, A <= 64 PPA.
+// Returns the number of children the node received, or -1 when it had children already or the node pool is full.
+template <int PPA>
+__device__ inline int expand_node(const Dev& d, int g, int lane, int node, const float* logits, const uint8_t* legal,
+                                  const double* noise, double* p_lds, double* priors_out) {
     const int A = d.A;
-    constexpr int PPA = 6;   // actions per lane: A <= 362
     double* q_lds = p_lds + A;
     bool lg_[PPA];
     double mx = -INFINITY;
@@ -875,7 +970,7 @@ __device__ inline void expand_node(const Dev& d, int g, int lane, int node, cons
             else d.n_nodes[g] = first + cnt;
         }
         first = __shfl(first, 0);
-        if (first < 0) return;
+        if (first < 0) return -1;
     }
     int pos[PPA];
     if (!topk) {
@@ -983,14 +1078,17 @@ __device__ inline void expand_node(const Dev& d, int g, int lane, int node, cons
     }
     __threadfence_block();
     __syncthreads();
+    return already ? -1 : cnt;
 }
 
 // Root expansion (mcts.py:172): one wave per game.
 // `enable` (may be null): games switched off after their root row was gathered leave the search here.
+template <int PPL>
 __global__ __launch_bounds__(64) void k_expand_root(Dev d, const float* logits, const double* noise, double* priors_out, const uint8_t* enable) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
     double* p_lds = (double*)dyn;
     const int g = blockIdx.x, lane = threadIdx.x;
+    if (g == 0 && lane == 0) { d.ctl[4] = 0; d.ctl[5] = 0; }   // the row counters of the batch rounds (az_mcts_run_rounds)
     if (lane < 8) d.gstats[(size_t)g * 8 + lane] = 0;   // a search's counters start here (k_begin clears them too)
     __syncthreads();
     if (!d.active[g]) return;
@@ -1001,79 +1099,89 @@ __global__ __launch_bounds__(64) void k_expand_root(Dev d, const float* logits, 
     }
     const int r = d.row_off[g];
     const float* lg = (d.rc_cap && d.root_cached[g]) ? d.root_logits + (size_t)g * d.A : logits + (size_t)r * d.A;
-    expand_node(d, g, lane, 0, lg, d.row_legal + (size_t)r * d.A,
-                noise ? noise + (size_t)g * d.A : nullptr, p_lds, priors_out ? priors_out + (size_t)r * d.A : nullptr);
+    expand_node<Apl<PPL>::v>(d, g, lane, 0, lg, d.row_legal + (size_t)r * d.A,
+                             noise ? noise + (size_t)g * d.A : nullptr, p_lds, priors_out ? priors_out + (size_t)r * d.A : nullptr);
 }
 
-// Expand the batch's leaves, then revert virtual loss and back up in slot order (mcts.py:203-218).
-__device__ __forceinline__ void expand_backup_body(const Dev& d, const float* logits, const float* values, int batch_n, double* priors_out) {
+// Expand the batch's leaves, then revert virtual loss and back up in slot order (mcts.py:203-218). Loads the root's
+// statistics into `rc` and leaves them updated there, not stored.
+template <int PPL>
+__device__ __forceinline__ void expand_backup_body(const Dev& d, const float* logits, const float* values, int batch_n, double* priors_out,
+                                                   RootCache<Apl<PPL>::v>& rc) {
+    constexpr int CPL = Apl<PPL>::v;
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
     double* p_lds = (double*)dyn;
     double* s_val = p_lds + 2 * d.A;          // [B] value each slot backs up
-    int* s_len = (int*)(s_val + d.B);         // [B] path length
-    int* s_n1 = s_len + d.B;                  // [B] path[1] (the root child), -1 for a path that ends at the root
-    const int g = blockIdx.x, lane = threadIdx.x;
-    if (!d.active[g]) return;
-    const int nu = d.n_unique[g], r0 = d.row_off[g];
+    int* s_rec = (int*)(s_val + d.B);         // [4 + 4 B] the batch record the descents left
+    const int g = blockIdx.x, lane = threadIdx.x, B = d.B;
     const size_t nb = (size_t)g * d.max_nodes;
+    {
+        const int* brec = d.brec + (size_t)g * brec_words(d);
+        for (int i = lane; i < brec_words(d); i += 64) s_rec[i] = brec[i];
+    }
+    const int r0 = d.row_off[g];
+    __syncthreads();
+    const int nu = s_rec[0];
+    const int* r_len = s_rec + 4; const int* r_n1 = r_len + B; const int* r_leaf = r_n1 + B; const int* r_uniq = r_leaf + B;
+    rc_load<CPL>(d, nb, lane, s_rec[2], s_rec[3], rc);
+    // the value every slot backs up: its leaf's evaluation, or the outcome of a terminal leaf
+    for (int s = lane; s < batch_n; s += 64) {
+        const int ref = (r_len[s] >> 16) - 1;
+        double value;
+        if (ref < 0) value = d.term_value[g * B + s];
+        else {
+            int u = 0;
+            for (; u < nu; ++u) if (r_uniq[u] == ref) break;
+            value = (double)values[r0 + u];
+        }
+        s_val[s] = value;
+    }
+    const bool cached = rc.held();
+    const int rfirst = rc.rfirst;
     for (int u = 0; u < nu; ++u) {
-        const int slot = d.uniq_slot[g * d.B + u];
-        const int plen = d.path_len[g * d.B + slot];
-        const int* path = d.path + ((size_t)g * d.B + slot) * d.max_depth;
-        const int node = path[plen - 1];
-        expand_node(d, g, lane, node, logits + (size_t)(r0 + u) * d.A, d.row_legal + (size_t)(r0 + u) * d.A, nullptr, p_lds,
-                    priors_out ? priors_out + (size_t)(r0 + u) * d.A : nullptr);
-        if (d.rc_cap && plen == 2) {   // a child of the root: a candidate for the next root
-            const int ci = node - d.child_off[nb];
-            if (ci >= 0 && ci < d.rc_cap) {
+        const int slot = r_uniq[u];
+        const int plen = r_len[slot] & 0xffff, node = r_leaf[slot];
+        const int made = expand_node<CPL>(d, g, lane, node, logits + (size_t)(r0 + u) * d.A, d.row_legal + (size_t)(r0 + u) * d.A, nullptr, p_lds,
+                                          priors_out ? priors_out + (size_t)(r0 + u) * d.A : nullptr);
+        if (plen == 2) {   // a child of the root
+            const int ci = node - rfirst;
+            if (made >= 0 && cached) {
+#pragma unroll
+                for (int k = 0; k < CPL; ++k)
+                    if (lane + 64 * k == ci) rc.nch[k] = made;
+            }
+            if (d.rc_cap && ci >= 0 && ci < d.rc_cap) {   // a candidate for the next root: keep its evaluation
                 float* dst = d.rc_logits + ((size_t)g * d.rc_cap + ci) * d.A;
                 for (int i = lane; i < d.A; i += 64) dst[i] = logits[(size_t)(r0 + u) * d.A + i];
                 if (lane == 0) d.rc_valid[(size_t)g * d.rc_cap + ci] = 1;
             }
         }
     }
+    __syncthreads();
     double* vsum = d.vsum + nb;
     int* visits = d.visits + nb;
-    // Per-slot facts, fetched by the lanes side by side (one dependent chain instead of one per slot)
-    for (int s = lane; s < batch_n; s += 64) {
-        const int gs = g * d.B + s;
-        const int ref = d.leaf_ref[gs];
-        double value;
-        if (ref < 0) value = d.term_value[gs];
-        else {
-            int u = 0;
-            for (; u < nu; ++u) if (d.uniq_slot[g * d.B + u] == ref) break;
-            value = (double)values[r0 + u];
-        }
-        const int len = d.path_len[gs];
-        s_val[s] = value;
-        s_len[s] = len;
-        s_n1[s] = len > 1 ? d.path[(size_t)gs * d.max_depth + 1] : -1;
-    }
-    __syncthreads();
-    // The root and its children (lane i: child i, when there are at most 64) keep their statistics in registers over the
-    // slots: every path starts there and, with virtual loss, most end there. Deeper nodes are updated in memory.
-    const int rnc = d.n_child[nb], rfirst = d.child_off[nb];
-    const bool cached = rnc > 0 && rnc <= 64;
-    double c_vsum = 0.0, r_vsum = vsum[0];
-    int c_vis = 0, r_vis = visits[0];
-    if (cached && lane < rnc) { c_vsum = vsum[rfirst + lane]; c_vis = visits[rfirst + lane]; }
+    // Deeper nodes than the root's children are updated in memory.
     const bool vl_on = d.vl > 0.0;
     for (int slot = 0; slot < batch_n; ++slot) {
         const double value = s_val[slot];
-        const int len = s_len[slot];
+        const int len = r_len[slot] & 0xffff;
         if (cached) {
             {   // root (i = 0)
                 const double v = ((len - 1) & 1) ? -value : value;
-                int vc = r_vis; double vs = r_vsum;
+                int vc = rc.r_vis; double vs = rc.r_vsum;
                 if (vl_on) { vc -= 1; vs += d.vl; }
-                r_vis = vc + 1; r_vsum = vs + v;
+                rc.r_vis = vc + 1; rc.r_vsum = vs + v;
             }
-            if (len > 1 && lane == s_n1[slot] - rfirst) {   // the root child (i = 1)
+            if (len > 1) {   // the root child (i = 1)
+                const int ci = r_n1[slot] - rfirst;
                 const double v = ((len - 2) & 1) ? -value : value;
-                int vc = c_vis; double vs = c_vsum;
-                if (vl_on) { vc -= 1; vs += d.vl; }
-                c_vis = vc + 1; c_vsum = vs + v;
+#pragma unroll
+                for (int k = 0; k < CPL; ++k)
+                    if (lane + 64 * k == ci) {
+                        int vc = rc.vis[k]; double vs = rc.vsum[k];
+                        if (vl_on) { vc -= 1; vs += d.vl; }
+                        rc.vis[k] = vc + 1; rc.vsum[k] = vs + v;
+                    }
             }
         }
         if (!cached || len > 2) {
@@ -1091,25 +1199,35 @@ __device__ __forceinline__ void expand_backup_body(const Dev& d, const float* lo
             __syncthreads();
         }
     }
-    if (cached) {
-        if (lane < rnc) { visits[rfirst + lane] = c_vis; vsum[rfirst + lane] = c_vsum; }
-        if (lane == 0) { visits[0] = r_vis; vsum[0] = r_vsum; }
-    }
 }
 
+template <int PPL>
 __global__ __launch_bounds__(64) void k_expand_backup(Dev d, const float* logits, const float* values, int batch_n, double* priors_out) {
-    expand_backup_body(d, logits, values, batch_n, priors_out);
+    if (!d.active[blockIdx.x]) return;
+    RootCache<Apl<PPL>::v> rc;
+    expand_backup_body<PPL>(d, logits, values, batch_n, priors_out, rc);
+    rc_store<Apl<PPL>::v>(d, (size_t)blockIdx.x * d.max_nodes, threadIdx.x, rc);
 }
 
 // Expansion + backup of one batch followed by the descents of the next, for the same game in the same wave: between the
-// two nothing crosses games (the row scan, the leaf gather and the network sit between a select and its expand), so a
-// search enqueued as a whole saves one launch and one kernel start-up per round.
+// two nothing crosses games (the leaf gather and the network sit between a select and its expand), so a search enqueued
+// as a whole saves a launch per round, the root's statistics stay in registers from the backup through the descents, and
+// the descents' rows are allotted from a counter (rows_ctr) instead of a scan over the games.
 template <int PPL>
-__global__ __launch_bounds__(64) void k_expand_select(Dev d, const float* logits, const float* values, int batch_prev, double* priors_out, int batch_next) {
-    expand_backup_body(d, logits, values, batch_prev, priors_out);
+__global__ __launch_bounds__(64) void k_expand_select(Dev d, const float* logits, const float* values, int batch_prev, double* priors_out, int batch_next,
+                                                      int* rows_ctr, int visits_hint) {
+    const int g = blockIdx.x, lane = threadIdx.x;
+    if (!d.active[g]) { if (lane == 0) d.n_unique[g] = 0; return; }
+    // independent of the expansion: the exploration-table entries of the coming descents, the root's pass / move counters
+    const int t_idx = min(visits_hint + (d.vl > 0.0 ? lane : 0), d.tab_len - 1);
+    const double t_pbc = d.pbc[t_idx], t_sqn = d.sqn[t_idx];
+    const int passes = d.sc[sc_idx(g, SC_PASSES)], moves = d.sc[sc_idx(g, SC_MOVES)];
+    RootCache<Apl<PPL>::v> rc;
+    expand_backup_body<PPL>(d, logits, values, batch_prev, priors_out, rc);
     __threadfence_block();
-    __syncthreads();   // the statistics written by the backup are read by the descents
-    select_body<PPL>(d, batch_next);
+    __syncthreads();   // deeper statistics written by the backup are read by the descents; the two phases share the LDS
+    select_body<PPL>(d, batch_next, rc, passes, moves, t_pbc, t_sqn, visits_hint, rows_ctr);
+    rc_store<Apl<PPL>::v>(d, (size_t)g * d.max_nodes, lane, rc);
 }
 
 __global__ __launch_bounds__(64) void k_root_counts(Dev d, int* counts) {
@@ -1243,8 +1361,8 @@ int az_engine_create(const az_config* c, az_engine** out) {
     ALLOC(path, (size_t)d.G * d.B * d.max_depth); ALLOC(path_len, (size_t)d.G * d.B); ALLOC(leaf_ref, (size_t)d.G * d.B);
     ALLOC(term_value, (size_t)d.G * d.B); ALLOC(n_unique, d.G); ALLOC(uniq_slot, (size_t)d.G * d.B);
     ALLOC(row_off, d.G + 1); ALLOC(row_game, d.max_rows); ALLOC(row_slot, d.max_rows);
-    ALLOC(row_legal, (size_t)d.max_rows * d.A); ALLOC(ctl, 4); ALLOC(stats, 8); ALLOC(gstats, (size_t)d.G * 8);
-    ALLOC(root_count, d.G);
+    ALLOC(row_legal, (size_t)d.max_rows * d.A); ALLOC(ctl, 8); ALLOC(stats, 8); ALLOC(gstats, (size_t)d.G * 8);
+    ALLOC(root_count, d.G); ALLOC(brec, (size_t)d.G * (4 + 4 * d.B));
     {
         int rc = dev_alloc(e, &e->last_priors, (size_t)d.max_rows * d.A);
         if (rc != AZ_OK) { az_engine_destroy(e); return rc; }
@@ -1277,7 +1395,8 @@ int az_engine_create(const az_config* c, az_engine** out) {
     d.zob = zdev; d.pbc = pdev; d.sqn = sdev;
     HIP_TRY_E(hipHostMalloc((void**)&e->ctl_host, 4 * sizeof(int)));
     HIP_TRY_E(hipHostMalloc((void**)&e->stats_host, 8 * sizeof(long long)));
-    HIP_TRY_E(hipMemset(d.ctl, 0, 4 * sizeof(int)));
+    HIP_TRY_E(hipMemset(d.ctl, 0, 8 * sizeof(int)));
+    HIP_TRY_E(hipMemset(d.brec, 0, (size_t)d.G * (4 + 4 * d.B) * sizeof(int)));
     HIP_TRY_E(hipMemset(d.stats, 0, 8 * sizeof(long long)));
     HIP_TRY_E(hipMemset(d.gstats, 0, (size_t)d.G * 8 * sizeof(long long)));
     int rc = az_rules_reset(e, nullptr, nullptr);
@@ -1369,16 +1488,19 @@ int az_mcts_begin(az_engine* e, const uint8_t* enable, void* stream) {
     return check_launch("k_begin");
 }
 
-// dynamic LDS of the descents: seen keys, then path, uniq pairs, staged len / ref / path[8], terminal-leaf cache (node, value)
+// dynamic LDS of the descents: seen keys, then path, uniq pairs, staged len / ref / root child / leaf / path[8], terminal-leaf
+// cache (node, value)
 static size_t select_shmem(const az_engine* e) {
-    return seen_bytes(e) + ((size_t)e->d.max_depth + (2 + 2 + 8 + 1 + 2) * (size_t)e->d.B) * 4;
+    return seen_bytes(e) + ((size_t)e->d.max_depth + (2 + 4 + 8 + 1 + 2) * (size_t)e->d.B) * 4;
 }
+// dynamic LDS of the expansion + backup: probabilities and ranking keys, per-slot values, the batch record
+static size_t expand_shmem(const az_engine* e) { return (size_t)e->d.A * 16 + (size_t)e->d.B * 24 + 64; }
 
 int az_mcts_select(az_engine* e, void* stream) {
     if (!e) return fail(AZ_ERR_ARG, "null engine");
     if (e->phase != PH_NEED_SELECT) return fail(AZ_ERR_STATE, "az_mcts_select: no batch to select (expand the pending rows first)");
     e->batch_n = std::min(e->d.B, e->d.sims - e->sims_done);
-    DISPATCH_PPL(e, k_select, e->d.G, select_shmem(e), stream, e->d, e->batch_n);
+    DISPATCH_PPL(e, k_select, e->d.G, select_shmem(e), stream, e->d, e->batch_n, (int*)nullptr, e->sims_done);
     hipLaunchKernelGGL(k_scan_rows, dim3(1), dim3(1024), 0, (hipStream_t)stream, e->d, 0);
     e->phase = PH_SELECTED;
     e->rows_known = false;
@@ -1464,7 +1586,7 @@ int az_mcts_gather(az_engine* e, void* out, int32_t layout, void* stream) {
     }
     if (grid == 0) return AZ_OK;
     const size_t shmem = seen_bytes(e) + (size_t)e->d.H * e->d.npad;
-    DISPATCH_PPL(e, k_leaf, grid, shmem, stream, e->d, out, layout);
+    DISPATCH_PPL(e, k_leaf, grid, shmem, stream, e->d, out, layout, (const int*)(e->d.ctl + 2), (int*)nullptr);
     return check_launch("k_leaf");
 }
 
@@ -1478,10 +1600,10 @@ int az_mcts_row_games(az_engine* e, int32_t* row_game, void* stream) {
 
 int az_mcts_expand(az_engine* e, const float* logits, const float* values, const double* noise, void* stream) {
     if (!e) return fail(AZ_ERR_ARG, "null engine");
-    const size_t shmem = (size_t)e->d.A * 16 + (size_t)e->d.B * 16 + 64;
+    const size_t shmem = expand_shmem(e);
     if (e->phase == PH_ROOT) {
         if (!logits && !(e->d.rc_cap && e->rows_known && e->pending_rows == 0)) return fail(AZ_ERR_ARG, "null logits");
-        hipLaunchKernelGGL(k_expand_root, dim3(e->d.G), dim3(64), shmem, (hipStream_t)stream, e->d, logits, noise, e->last_priors, e->root_enable);
+        DISPATCH_PPL(e, k_expand_root, e->d.G, shmem, stream, e->d, logits, noise, e->last_priors, e->root_enable);
     } else if (e->phase == PH_SELECTED) {
         if (!e->async_mode) {
             int rc = need_rows(e, stream);
@@ -1490,8 +1612,7 @@ int az_mcts_expand(az_engine* e, const float* logits, const float* values, const
         } else if (!logits || !values) {
             return fail(AZ_ERR_ARG, "null logits/values");
         }
-        hipLaunchKernelGGL(k_expand_backup, dim3(e->d.G), dim3(64), shmem, (hipStream_t)stream, e->d, logits, values,
-                           e->batch_n, e->last_priors);
+        DISPATCH_PPL(e, k_expand_backup, e->d.G, shmem, stream, e->d, logits, values, e->batch_n, e->last_priors);
         e->sims_done += e->batch_n;
     } else {
         return fail(AZ_ERR_STATE, "az_mcts_expand: nothing pending");
@@ -1506,25 +1627,35 @@ int az_mcts_expand(az_engine* e, const float* logits, const float* values, const
 }
 
 // Enqueue the batch rounds from the engine's state (az_mcts_select .. az_mcts_expand until the simulations are used up).
+// Round r: the descents of batch r (alone for the first, behind the expansion of batch r-1 afterwards) allot their rows from
+// counter r & 1 (d.ctl[4 + (r & 1)]), the leaf gather and the network read that counter, and the gather clears the other one
+// for round r+1 (whose readers, the gather and the network of round r-1, are done by then).
 static int enqueue_rounds(az_engine* e, az_net* net, void* feat, int32_t layout, float* logits, float* values, void* stream) {
+    if (e->phase != PH_NEED_SELECT) return fail(AZ_ERR_STATE, "no batch to select (expand the pending rows first)");
     const int32_t max_rows = std::max(e->d.max_rows, e->d.G);
-    int rc = az_mcts_select(e, stream);
-    if (rc != AZ_OK) return rc;
+    const size_t leaf_shmem = seen_bytes(e) + (size_t)e->d.H * e->d.npad;
+    int parity = 0;
+    e->batch_n = std::min(e->d.B, e->d.sims - e->sims_done);
+    DISPATCH_PPL(e, k_select, e->d.G, select_shmem(e), stream, e->d, e->batch_n, e->d.ctl + 4 + parity, e->sims_done);
+    e->phase = PH_SELECTED;
+    e->rows_known = false;
     for (;;) {
-        rc = az_mcts_gather(e, feat, layout, stream);
+        DISPATCH_PPL(e, k_leaf, e->d.max_rows, leaf_shmem, stream, e->d, feat, layout, (const int*)(e->d.ctl + 4 + parity), e->d.ctl + 4 + (parity ^ 1));
+        int rc = check_launch("k_leaf");
         if (rc != AZ_OK) return rc;
-        rc = az_net_forward_indirect(net, feat, e->d.ctl, max_rows, logits, values, stream);
+        rc = az_net_forward_indirect(net, feat, e->d.ctl + 4 + parity, max_rows, logits, values, stream);
         if (rc != AZ_OK) return rc;
         const int left = e->d.sims - (e->sims_done + e->batch_n);
         if (left <= 0) {   // the last batch: expansion and backup only
             rc = az_mcts_expand(e, logits, values, nullptr, stream);
             return rc < 0 ? rc : AZ_OK;
         }
-        // expansion + backup of this batch and the descents of the next in one launch, then the row scan
+        // expansion + backup of this batch and the descents of the next in one launch
         const int batch_next = std::min(e->d.B, left);
-        const size_t shmem = std::max((size_t)e->d.A * 16 + (size_t)e->d.B * 16 + 64, select_shmem(e));
-        DISPATCH_PPL(e, k_expand_select, e->d.G, shmem, stream, e->d, (const float*)logits, (const float*)values, e->batch_n, e->last_priors, batch_next);
-        hipLaunchKernelGGL(k_scan_rows, dim3(1), dim3(1024), 0, (hipStream_t)stream, e->d, 0);
+        const size_t shmem = std::max(expand_shmem(e), select_shmem(e));
+        parity ^= 1;
+        DISPATCH_PPL(e, k_expand_select, e->d.G, shmem, stream, e->d, (const float*)logits, (const float*)values, e->batch_n, e->last_priors, batch_next,
+                     e->d.ctl + 4 + parity, e->sims_done + e->batch_n);
         rc = check_launch("k_expand_select");
         if (rc != AZ_OK) return rc;
         e->sims_done += e->batch_n;
