@@ -82,6 +82,17 @@ struct Dev {
     int* ctl_mirror;   // null, or [4]: the root-phase row scan also leaves its counts here (a self-play lane's record)
 };
 
+// -DAZ_ESTAMP (diagnostic builds, tools/estamp_probe.py): lane 0 of every wave of the search kernels leaves the 100 MHz
+// real-time counter at phase boundaries; az_debug_estamps copies the table out. The regular build has no stamps.
+#ifdef AZ_ESTAMP
+__device__ unsigned long long g_estamp[4096 * 16];
+#define ESTAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_estamp[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define ESTAMP_CYCLES(i) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_estamp[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define ESTAMP(i) do {} while (0)
+#define ESTAMP_CYCLES(i) do {} while (0)
+#endif
+
 __device__ inline int sc_idx(int g, int f) { return g * 8 + f; }
 enum { SC_TP = 0, SC_PASSES, SC_MOVES, SC_CAPB, SC_CAPW, SC_LAST, SC_HIST, SC_SEEN };
 
@@ -537,6 +548,21 @@ __device__ inline void wave_argmax(double& s, int& idx) {
     s = m; idx = __builtin_amdgcn_readlane(cand, 63);
 }
 
+// Wave maximum of a float by the same DPP steps as wave_max_f64 (NaN operands lose: maxNum).
+__device__ inline float wave_max_f32(float v) {
+    auto step = [&](auto ctrl, auto row_mask) {
+        const int o = __builtin_amdgcn_update_dpp((int)0xFF800000, __float_as_int(v), decltype(ctrl)::value, decltype(row_mask)::value, 0xf, false);
+        v = fmaxf(v, __int_as_float(o));
+    };
+    step(std::integral_constant<int, 0x111>{}, std::integral_constant<int, 0xf>{});
+    step(std::integral_constant<int, 0x112>{}, std::integral_constant<int, 0xf>{});
+    step(std::integral_constant<int, 0x114>{}, std::integral_constant<int, 0xf>{});
+    step(std::integral_constant<int, 0x118>{}, std::integral_constant<int, 0xf>{});
+    step(std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});
+    step(std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
 // Actions (and root children) per lane in the search kernels of a board class: boards up to 11x11 have at most 122 actions
 // (2 per lane), 12x12 and 13x13 at most 170 (3), boards up to 19x19 at most 362 (6).
 template <int PPL> struct Apl { static constexpr int v = PPL <= 2 ? 2 : PPL; };
@@ -636,10 +662,85 @@ __device__ __forceinline__ void select_body(const Dev& d, int batch_n, RootCache
         t_pbc = d.pbc[t_idx]; t_sqn = d.sqn[t_idx];
     }
     const int r_vis0 = rc.r_vis;
+    // float copies of the root children's priors and value sums and of the exploration-table entries for the interval
+    // pre-selection below
+    const float t_pbc32 = (float)t_pbc, t_sqn32 = (float)t_sqn;
+    float pr32[CPL], vs32[CPL];
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) { pr32[k] = (float)rc.prior[k]; vs32[k] = (float)rc.vsum[k]; }
+    int last_node = -1, last_ref = -1;   // the distinct leaf found last (most descents of a batch end in it again)
     for (int slot = 0; slot < batch_n; ++slot) {
+        if (slot == 1) { ESTAMP(8); ESTAMP_CYCLES(12); }
+        // The usual descent ends in a child of the root that has no children yet: handled here without the general loop.
+        // Pre-selection in float with error intervals: a child's float score sc and a bound e on its distance from the
+        // float64 score of mcts.py:104-108 (at most eleven roundings of 2^-23 relative each on the exploration and the value
+        // term: below 1.4e-6 (|u| + |q|); e takes 4e-6). Only children with sc + e >= max(sc - e) can hold the float64
+        // maximum; when exactly one does, it is the child the float64 arg-max returns, and the float64 scores are not
+        // needed. Ties, near-ties and every other kind of descent take the general loop below.
+        {
+            const int tslot = d.vl > 0.0 ? rc.r_vis - r_vis0 : 0;
+            if (cached && tslot < 64 && root_passes < 2 && root_moves + 1 < 2 * d.np && d.max_depth > 2) {
+                const float pbc32 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t_pbc32), tslot));
+                const float sq32 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t_sqn32), tslot));
+                float hi[CPL], lo = -INFINITY;
+#pragma unroll
+                for (int k = 0; k < CPL; ++k) {
+                    const bool valid = lane + 64 * k < rnc;
+                    const int vc = rc.vis[k];
+                    const float fvc = (float)vc;
+                    const float u = pbc32 * (sq32 * __builtin_amdgcn_rcpf(fvc + 1.0f)) * pr32[k];
+                    const float q = vc == 0 ? 0.0f : vs32[k] * __builtin_amdgcn_rcpf(fvc);
+                    const float sc = u - q, e = 4e-6f * (fabsf(u) + fabsf(q)) + 1e-30f;
+                    hi[k] = valid ? sc + e : -INFINITY;
+                    lo = fmaxf(lo, valid ? sc - e : -INFINITY);
+                }
+                const float m_lo = wave_max_f32(lo);
+                int total = 0, ci = 0;
+#pragma unroll
+                for (int k = 0; k < CPL; ++k) {
+                    const unsigned long long bal = __ballot(hi[k] >= m_lo);
+                    total += __popcll(bal);
+                    if (bal) ci = 64 * k + __ffsll((long long)bal) - 1;
+                }
+                if (total == 1 && m_lo > -1e17f) {   // (scores at or below -1e18 never win: mcts.py:100, :109)
+                    const int nchc = rc_read<CPL>(rc.nch, ci), actc = rc_read<CPL>(rc.act, ci);
+                    const int passes1 = actc == d.np ? root_passes + 1 : 0;
+                    if (nchc == 0 && passes1 < 2) {
+                        const int node = rfirst + ci;
+                        if (lane < 2) st_path[slot * PSTAGE + lane] = lane == 0 ? 0 : node;
+                        int ref = slot;
+                        if (d.dedup) {
+                            if (node == last_node) ref = last_ref;
+                            else
+                                for (int u = 0; u < n_unique; ++u)
+                                    if (uniq_lds[2 * u + 1] == node) { ref = uniq_lds[2 * u]; break; }
+                        }
+                        if (lane == 0) {
+                            if (ref == slot) { uniq_lds[2 * n_unique] = slot; uniq_lds[2 * n_unique + 1] = node; }
+                            st_len[slot] = 2; st_ref[slot] = ref; st_n1[slot] = node; st_leaf[slot] = node;
+                        }
+                        if (ref == slot) n_unique += 1;
+                        last_node = node; last_ref = ref;
+                        depth_sum += 1;
+                        max_depth = max(max_depth, 1);
+                        if (d.vl > 0.0) {  // mcts.py:196-199
+                            rc.r_vis += 1;
+                            rc.r_vsum -= d.vl;
+#pragma unroll
+                            for (int k = 0; k < CPL; ++k)
+                                if (lane + 64 * k == ci) { rc.vis[k] += 1; rc.vsum[k] -= d.vl; vs32[k] = (float)rc.vsum[k]; }
+                        }
+                        wave_sync();
+                        if (slot == 1) { ESTAMP(9); ESTAMP(10); ESTAMP(11); ESTAMP_CYCLES(13); }
+                        continue;
+                    }
+                }
+            }
+        }
         int* path = d.path + ((size_t)g * d.B + slot) * d.max_depth;
         int node = 0, len = 1, nc = rnc;
         int child_vis = -1;   // visit count of the current node when it is a root child held in registers
+        int root_child = -1;  // index of the root child the descent went through
         int passes = root_passes, moves = root_moves;
         if (lane == 0) path_lds[0] = 0;
         bool failed = false;
@@ -664,7 +765,8 @@ __device__ __forceinline__ void select_body(const Dev& d, int batch_n, RootCache
                 for (int k = 0; k < CPL; ++k) {
                     const int i = lane + 64 * k;
                     if (i < nc) {
-                        const int vc = rc.vis[k];
+                        int vc = rc.vis[k];
+                        asm volatile("" : "+v"(vc));   // keeps these divisions here: hoisted, they would run in front of every short descent
                         double pb = pbc * (sq / ((double)vc + 1.0));
                         const double prior_score = pb * rc.prior[k];
                         const double value_score = -(vc == 0 ? 0.0 : rc.vsum[k] / (double)vc);
@@ -688,6 +790,7 @@ __device__ __forceinline__ void select_body(const Dev& d, int batch_n, RootCache
             wave_argmax(best, best_i);
             if (best_i == 0x7fffffff) { failed = true; break; }  // mcts.py:114-115
             node = first + best_i;
+            if (at_root) root_child = best_i;
             // best_i is wave-uniform (wave_argmax returns it from one lane)
             const int act = at_root ? rc_read<CPL>(rc.act, best_i) : (int)action[node];
             nc = at_root ? rc_read<CPL>(rc.nch, best_i) : (int)n_child[node];
@@ -698,8 +801,10 @@ __device__ __forceinline__ void select_body(const Dev& d, int batch_n, RootCache
             len += 1;
         }
         if (failed) { if (lane == 0) atomicMin(&d.ctl[1], (int)AZ_ERR_NOCHILD); }
+        if (slot == 1) ESTAMP(9);
         wave_sync();
-        if (len <= PSTAGE) { if (lane < len) st_path[slot * PSTAGE + lane] = path_lds[lane]; }
+        if (len == 2 && root_child >= 0) { if (lane < 2) st_path[slot * PSTAGE + lane] = lane == 0 ? 0 : node; }   // root -> child, the usual path
+        else if (len <= PSTAGE) { if (lane < len) st_path[slot * PSTAGE + lane] = path_lds[lane]; }
         else for (int i = lane; i < len; i += 64) path[i] = path_lds[i];
         const bool terminal = passes >= 2 || moves >= 2 * d.np;
         const int gs = g * d.B + slot;
@@ -728,8 +833,10 @@ __device__ __forceinline__ void select_body(const Dev& d, int batch_n, RootCache
         } else {
             ref = slot;
             if (d.dedup) {
-                for (int u = 0; u < n_unique; ++u)
-                    if (uniq_lds[2 * u + 1] == node) { ref = uniq_lds[2 * u]; break; }
+                if (node == last_node) ref = last_ref;
+                else
+                    for (int u = 0; u < n_unique; ++u)
+                        if (uniq_lds[2 * u + 1] == node) { ref = uniq_lds[2 * u]; break; }
             }
             if (ref == slot) {
                 if (lane == 0) {
@@ -738,20 +845,23 @@ __device__ __forceinline__ void select_body(const Dev& d, int batch_n, RootCache
                 }
                 n_unique += 1;
             }
+            last_node = node; last_ref = ref;
         }
-        if (lane == 0) { st_len[slot] = len; st_ref[slot] = ref; st_n1[slot] = len > 1 ? path_lds[1] : -1; st_leaf[slot] = node; }
+        const int n1 = len > 1 ? (root_child >= 0 ? rfirst + root_child : path_lds[1]) : -1;   // the root child on the path
+        if (lane == 0) { st_len[slot] = len; st_ref[slot] = ref; st_n1[slot] = n1; st_leaf[slot] = node; }
         depth_sum += len - 1;
         max_depth = max(max_depth, len - 1);
         wave_sync();
+        if (slot == 1) ESTAMP(10);
         if (d.vl > 0.0) {  // mcts.py:196-199
             if (cached) {
                 rc.r_vis += 1;
                 rc.r_vsum -= d.vl;
                 if (len > 1) {
-                    const int ci = path_lds[1] - rfirst;
+                    const int ci = n1 - rfirst;
 #pragma unroll
                     for (int k = 0; k < CPL; ++k)
-                        if (lane + 64 * k == ci) { rc.vis[k] += 1; rc.vsum[k] -= d.vl; }
+                        if (lane + 64 * k == ci) { rc.vis[k] += 1; rc.vsum[k] -= d.vl; vs32[k] = (float)rc.vsum[k]; }
                 }
             }
             for (int i = (cached ? 2 : 0) + lane; i < len; i += 64) {
@@ -761,7 +871,9 @@ __device__ __forceinline__ void select_body(const Dev& d, int batch_n, RootCache
             }
         }
         wave_sync();
+        if (slot == 1) { ESTAMP(11); ESTAMP_CYCLES(13); }
     }
+    ESTAMP(5);
     // the batch's results: the record for the expansion, the path lengths and slot tables the leaf gather reads
     int* brec = d.brec + (size_t)g * brec_words(d);
     for (int sl = lane; sl < batch_n; sl += 64) {
@@ -783,6 +895,7 @@ __device__ __forceinline__ void select_body(const Dev& d, int batch_n, RootCache
         row0 = __builtin_amdgcn_readfirstlane(row0);
         for (int u = lane; u < n_unique; u += 64) { d.row_game[row0 + u] = g; d.row_slot[row0 + u] = uniq_lds[2 * u]; }
     }
+    ESTAMP(6);
     if (lane == 0) {
         brec[0] = n_unique; brec[1] = 0; brec[2] = rnc; brec[3] = rfirst;
         if (rows_ctr) d.row_off[g] = row0;
@@ -1121,6 +1234,7 @@ __device__ __forceinline__ void expand_backup_body(const Dev& d, const float* lo
     }
     const int r0 = d.row_off[g];
     __syncthreads();
+    ESTAMP(1);
     const int nu = s_rec[0];
     const int* r_len = s_rec + 4; const int* r_n1 = r_len + B; const int* r_leaf = r_n1 + B; const int* r_uniq = r_leaf + B;
     rc_load<CPL>(d, nb, lane, s_rec[2], s_rec[3], rc);
@@ -1136,6 +1250,7 @@ __device__ __forceinline__ void expand_backup_body(const Dev& d, const float* lo
         }
         s_val[s] = value;
     }
+    ESTAMP(2);
     const bool cached = rc.held();
     const int rfirst = rc.rfirst;
     for (int u = 0; u < nu; ++u) {
@@ -1158,6 +1273,7 @@ __device__ __forceinline__ void expand_backup_body(const Dev& d, const float* lo
         }
     }
     __syncthreads();
+    ESTAMP(3);
     double* vsum = d.vsum + nb;
     int* visits = d.visits + nb;
     // Deeper nodes than the root's children are updated in memory.
@@ -1223,11 +1339,14 @@ __global__ __launch_bounds__(64) void k_expand_select(Dev d, const float* logits
     const double t_pbc = d.pbc[t_idx], t_sqn = d.sqn[t_idx];
     const int passes = d.sc[sc_idx(g, SC_PASSES)], moves = d.sc[sc_idx(g, SC_MOVES)];
     RootCache<Apl<PPL>::v> rc;
+    ESTAMP(0);
     expand_backup_body<PPL>(d, logits, values, batch_prev, priors_out, rc);
     __threadfence_block();
     __syncthreads();   // deeper statistics written by the backup are read by the descents; the two phases share the LDS
+    ESTAMP(4);
     select_body<PPL>(d, batch_next, rc, passes, moves, t_pbc, t_sqn, visits_hint, rows_ctr);
     rc_store<Apl<PPL>::v>(d, (size_t)g * d.max_nodes, lane, rc);
+    ESTAMP(7);
 }
 
 __global__ __launch_bounds__(64) void k_root_counts(Dev d, int* counts) {
@@ -1739,5 +1858,13 @@ int az_mcts_stats(az_engine* e, int64_t* out, void* stream) {
 }
 
 }  // extern "C"
+
+#ifdef AZ_ESTAMP
+extern "C" int az_debug_estamps(unsigned long long* out, int words) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_estamp), (size_t)words * 8));
+    return AZ_OK;
+}
+#endif
 
 #include "az_lane.cuh"
