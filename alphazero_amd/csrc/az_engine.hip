@@ -548,19 +548,23 @@ __device__ inline void wave_argmax(double& s, int& idx) {
     s = m; idx = __builtin_amdgcn_readlane(cand, 63);
 }
 
-// Wave maximum of a float by the same DPP steps as wave_max_f64 (NaN operands lose: maxNum).
-__device__ inline float wave_max_f32(float v) {
-    auto step = [&](auto ctrl, auto row_mask) {
-        const int o = __builtin_amdgcn_update_dpp((int)0xFF800000, __float_as_int(v), decltype(ctrl)::value, decltype(row_mask)::value, 0xf, false);
-        v = fmaxf(v, __int_as_float(o));
-    };
-    step(std::integral_constant<int, 0x111>{}, std::integral_constant<int, 0xf>{});
-    step(std::integral_constant<int, 0x112>{}, std::integral_constant<int, 0xf>{});
-    step(std::integral_constant<int, 0x114>{}, std::integral_constant<int, 0xf>{});
-    step(std::integral_constant<int, 0x118>{}, std::integral_constant<int, 0xf>{});
-    step(std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});
-    step(std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+// Wave maximum of floats (no NaNs among them, or a NaN may win) through the order-preserving integer key of a float
+// (sign-magnitude to two's complement), so that every step is one v_max_i32 with a DPP operand: lanes a step does not
+// reach keep their value.
+__device__ inline int float_key(float f) {
+    const int b = __float_as_int(f);
+    return b ^ ((b >> 31) & 0x7fffffff);
+}
+__device__ inline float key_float(int k) { return __int_as_float(k ^ ((k >> 31) & 0x7fffffff)); }
+__device__ inline float wave_max_f32(float f) {
+    int v = float_key(f);
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x111, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x112, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x114, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x118, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x142, 0xa, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x143, 0xc, 0xf, false));
+    return key_float(__builtin_amdgcn_readlane(v, 63));
 }
 
 // Actions (and root children) per lane in the search kernels of a board class: boards up to 11x11 have at most 122 actions
@@ -575,7 +579,11 @@ struct RootCache {
     double r_vsum;
     double prior[CPL], vsum[CPL];
     int vis[CPL], nch[CPL], act[CPL];
+    int cf[CPL];   // child_off of the child: index of its first child, or the outcome code of a terminal one (term_code)
     __device__ bool held() const { return rnc > 0 && rnc <= 64 * CPL; }
+    // what a short descent needs to know about child k in one word: children (10 bits), action (10 bits), outcome code + 1
+    // of a terminal child whose outcome is known (0: not known; 2 bits)
+    __device__ int packed(int k) const { return nch[k] | (act[k] << 10) | ((cf[k] <= -2 ? -cf[k] - 1 : 0) << 20); }
 };
 
 template <int CPL>
@@ -585,10 +593,11 @@ __device__ inline void rc_load(const Dev& d, size_t nb, int lane, int rnc, int r
 #pragma unroll
     for (int k = 0; k < CPL; ++k) {
         const int i = lane + 64 * k;
-        c.prior[k] = 0.0; c.vsum[k] = 0.0; c.vis[k] = 0; c.nch[k] = 0; c.act[k] = 0;
+        c.prior[k] = 0.0; c.vsum[k] = 0.0; c.vis[k] = 0; c.nch[k] = 0; c.act[k] = 0; c.cf[k] = 0;
         if (c.held() && i < rnc) {
             const size_t x = nb + rfirst + i;
             c.prior[k] = d.prior[x]; c.vsum[k] = d.vsum[x]; c.vis[k] = d.visits[x]; c.nch[k] = d.n_child[x]; c.act[k] = d.action[x];
+            c.cf[k] = d.child_off[x];
         }
     }
 }
@@ -603,6 +612,13 @@ __device__ inline void rc_store(const Dev& d, size_t nb, int lane, const RootCac
     }
     if (lane == 0) { d.visits[nb] = c.r_vis; d.vsum[nb] = c.r_vsum; }
 }
+
+// A terminal node never gets children, so its child_off field is free: once its outcome (go.py:251-263: +1, -1 or 0 from the
+// side to move) has been computed by replaying the path, it is kept there as -2 - (outcome + 1), and later descents that
+// end in the node read it instead of replaying.
+__device__ inline int term_code(double outcome) { return -2 - ((int)outcome + 1); }
+__device__ inline bool is_term_code(int child_off) { return child_off <= -2; }
+__device__ inline double term_outcome(int child_off) { return (double)(-child_off - 3); }
 
 // arr[idx >> 6] of lane idx & 63; idx must be wave-uniform
 template <int CPL>
@@ -669,8 +685,22 @@ __device__ __forceinline__ void select_body(const Dev& d, int batch_n, RootCache
 #pragma unroll
     for (int k = 0; k < CPL; ++k) { pr32[k] = (float)rc.prior[k]; vs32[k] = (float)rc.vsum[k]; }
     int last_node = -1, last_ref = -1;   // the distinct leaf found last (most descents of a batch end in it again)
+    int guess = -1;                      // the root child chosen last (with virtual loss, usually chosen again)
+    // Per-descent results: lane s keeps those of slot s in registers (slots from 64 on: LDS) until they are written out
+    int my_len = 0, my_ref = 0, my_n1 = 0, my_leaf = 0;
+    auto put_record = [&](int slot, int len, int ref, int n1, int leaf) {   // slot is wave-uniform
+        if (slot < 64) {
+            const bool me = lane == slot;
+            my_len = me ? len : my_len; my_ref = me ? ref : my_ref; my_n1 = me ? n1 : my_n1; my_leaf = me ? leaf : my_leaf;
+        } else if (lane == 0) {
+            st_len[slot] = len; st_ref[slot] = ref; st_n1[slot] = n1; st_leaf[slot] = leaf;
+        }
+    };
+    int pk[CPL];   // rc.packed(k), kept up to date where a child's fields change
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) pk[k] = rc.packed(k);
     for (int slot = 0; slot < batch_n; ++slot) {
-        if (slot == 1) { ESTAMP(8); ESTAMP_CYCLES(12); }
+        if (slot < 8) ESTAMP_CYCLES(8 + slot);
         // The usual descent ends in a child of the root that has no children yet: handled here without the general loop.
         // Pre-selection in float with error intervals: a child's float score sc and a bound e on its distance from the
         // float64 score of mcts.py:104-108 (at most eleven roundings of 2^-23 relative each on the exploration and the value
@@ -679,10 +709,10 @@ __device__ __forceinline__ void select_body(const Dev& d, int batch_n, RootCache
         // needed. Ties, near-ties and every other kind of descent take the general loop below.
         {
             const int tslot = d.vl > 0.0 ? rc.r_vis - r_vis0 : 0;
-            if (cached && tslot < 64 && root_passes < 2 && root_moves + 1 < 2 * d.np && d.max_depth > 2) {
+            if (cached && tslot < 64 && root_passes < 2 && root_moves < 2 * d.np && d.max_depth > 2) {
                 const float pbc32 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t_pbc32), tslot));
                 const float sq32 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t_sqn32), tslot));
-                float hi[CPL], lo = -INFINITY;
+                float hi[CPL], lo_k[CPL], lo = -INFINITY;
 #pragma unroll
                 for (int k = 0; k < CPL; ++k) {
                     const bool valid = lane + 64 * k < rnc;
@@ -692,47 +722,72 @@ __device__ __forceinline__ void select_body(const Dev& d, int batch_n, RootCache
                     const float q = vc == 0 ? 0.0f : vs32[k] * __builtin_amdgcn_rcpf(fvc);
                     const float sc = u - q, e = 4e-6f * (fabsf(u) + fabsf(q)) + 1e-30f;
                     hi[k] = valid ? sc + e : -INFINITY;
-                    lo = fmaxf(lo, valid ? sc - e : -INFINITY);
+                    lo_k[k] = valid ? sc - e : -INFINITY;
+                    lo = fmaxf(lo, lo_k[k]);
                 }
-                const float m_lo = wave_max_f32(lo);
+                // first against the lower bound of the child chosen last: if no other child's upper bound reaches it, that
+                // child holds the maximum again and the wave-wide maximum is not needed
+                float m_lo = -INFINITY;
                 int total = 0, ci = 0;
+                if (guess >= 0) {
+                    float lo_g = -INFINITY;
 #pragma unroll
-                for (int k = 0; k < CPL; ++k) {
-                    const unsigned long long bal = __ballot(hi[k] >= m_lo);
-                    total += __popcll(bal);
-                    if (bal) ci = 64 * k + __ffsll((long long)bal) - 1;
+                    for (int k = 0; k < CPL; ++k) lo_g = lane + 64 * k == guess ? lo_k[k] : lo_g;
+                    m_lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lo_g), guess & 63));
+#pragma unroll
+                    for (int k = 0; k < CPL; ++k) total += __popcll(__ballot(hi[k] >= m_lo));
+                    ci = guess;
+                }
+                if (total != 1) {
+                    m_lo = wave_max_f32(lo);
+                    total = 0;
+#pragma unroll
+                    for (int k = 0; k < CPL; ++k) {
+                        const unsigned long long bal = __ballot(hi[k] >= m_lo);
+                        total += __popcll(bal);
+                        if (bal) ci = 64 * k + __ffsll((long long)bal) - 1;
+                    }
                 }
                 if (total == 1 && m_lo > -1e17f) {   // (scores at or below -1e18 never win: mcts.py:100, :109)
-                    const int nchc = rc_read<CPL>(rc.nch, ci), actc = rc_read<CPL>(rc.act, ci);
+                        int word = 0;
+#pragma unroll
+                    for (int k = 0; k < CPL; ++k) word = lane + 64 * k == ci ? pk[k] : word;
+                    word = __builtin_amdgcn_readlane(word, ci & 63);
+                    const int nchc = word & 1023, actc = (word >> 10) & 1023;
                     const int passes1 = actc == d.np ? root_passes + 1 : 0;
-                    if (nchc == 0 && passes1 < 2) {
+                    const bool terminal1 = passes1 >= 2 || root_moves + 1 >= 2 * d.np;
+                    const int cfc = (word >> 20) ? -(word >> 20) - 1 : 0;
+                    if (nchc == 0 && (!terminal1 || is_term_code(cfc))) {
                         const int node = rfirst + ci;
-                        if (lane < 2) st_path[slot * PSTAGE + lane] = lane == 0 ? 0 : node;
+                                guess = ci;
                         int ref = slot;
-                        if (d.dedup) {
+                        if (terminal1) {   // mcts.py:191-192, outcome known from an earlier descent
+                            ref = -1;
+                            n_term += 1;
+                            if (lane == 0) d.term_value[g * d.B + slot] = term_outcome(cfc);
+                        } else if (d.dedup) {
                             if (node == last_node) ref = last_ref;
                             else
                                 for (int u = 0; u < n_unique; ++u)
                                     if (uniq_lds[2 * u + 1] == node) { ref = uniq_lds[2 * u]; break; }
                         }
-                        if (lane == 0) {
-                            if (ref == slot) { uniq_lds[2 * n_unique] = slot; uniq_lds[2 * n_unique + 1] = node; }
-                            st_len[slot] = 2; st_ref[slot] = ref; st_n1[slot] = node; st_leaf[slot] = node;
+                        if (ref == slot) {
+                            if (lane == 0) { uniq_lds[2 * n_unique] = slot; uniq_lds[2 * n_unique + 1] = node; }
+                            n_unique += 1;
                         }
-                        if (ref == slot) n_unique += 1;
-                        last_node = node; last_ref = ref;
+                        put_record(slot, 2, ref, node, node);
+                        if (!terminal1) { last_node = node; last_ref = ref; }
                         depth_sum += 1;
                         max_depth = max(max_depth, 1);
-                        if (d.vl > 0.0) {  // mcts.py:196-199
+                                if (d.vl > 0.0) {  // mcts.py:196-199
                             rc.r_vis += 1;
                             rc.r_vsum -= d.vl;
 #pragma unroll
                             for (int k = 0; k < CPL; ++k)
                                 if (lane + 64 * k == ci) { rc.vis[k] += 1; rc.vsum[k] -= d.vl; vs32[k] = (float)rc.vsum[k]; }
                         }
-                        wave_sync();
-                        if (slot == 1) { ESTAMP(9); ESTAMP(10); ESTAMP(11); ESTAMP_CYCLES(13); }
-                        continue;
+                                wave_sync();
+                                continue;
                     }
                 }
             }
@@ -748,7 +803,7 @@ __device__ __forceinline__ void select_body(const Dev& d, int batch_n, RootCache
             if (nc == 0 || passes >= 2 || moves >= 2 * d.np || len >= d.max_depth) break;
             // mcts.py:97-116
             const bool at_root = cached && node == 0;
-            const int first = at_root ? rfirst : child_off[node];
+            const int first = at_root ? rfirst : ((len == 2 && root_child >= 0) ? rc_read<CPL>(rc.cf, root_child) : child_off[node]);
             double pbc, sq;
             const int tslot = d.vl > 0.0 ? rc.r_vis - r_vis0 : 0;   // = slot with virtual loss
             if (at_root && tslot < 64) {   // wave-uniform: register reads, no lane shuffle
@@ -801,9 +856,8 @@ __device__ __forceinline__ void select_body(const Dev& d, int batch_n, RootCache
             len += 1;
         }
         if (failed) { if (lane == 0) atomicMin(&d.ctl[1], (int)AZ_ERR_NOCHILD); }
-        if (slot == 1) ESTAMP(9);
         wave_sync();
-        if (len == 2 && root_child >= 0) { if (lane < 2) st_path[slot * PSTAGE + lane] = lane == 0 ? 0 : node; }   // root -> child, the usual path
+        if (len == 2) {}   // root -> child: written out from the record
         else if (len <= PSTAGE) { if (lane < len) st_path[slot * PSTAGE + lane] = path_lds[lane]; }
         else for (int i = lane; i < len; i += 64) path[i] = path_lds[i];
         const bool terminal = passes >= 2 || moves >= 2 * d.np;
@@ -814,8 +868,12 @@ __device__ __forceinline__ void select_body(const Dev& d, int batch_n, RootCache
             for (int u = 0; u < n_tc; ++u)
                 if (tc_node[u] == node) { hit = u; break; }
             double v;
+            int known = 0;
+            if (hit < 0) known = (len == 2 && root_child >= 0) ? rc_read<CPL>(rc.cf, root_child) : child_off[node];
             if (hit >= 0) {
                 v = tc_val[hit];
+            } else if (is_term_code(known)) {
+                v = term_outcome(known);
             } else {
                 Geo<PPL> geo;
                 geo_init<PPL>(geo, d.n, lane);
@@ -824,8 +882,13 @@ __device__ __forceinline__ void select_body(const Dev& d, int batch_n, RootCache
                 sim_load_root<PPL>(d, g, lane, geo, b, seen_lds, s);
                 for (int i = 1; i < len; ++i) sim_play<PPL>(d, lane, geo, b, seen_lds, nullptr, s, (int)action[path_lds[i]]);
                 v = sim_outcome<PPL>(d, geo, b, s);
-                if (lane == 0) { tc_node[n_tc] = node; tc_val[n_tc] = v; }
+                if (lane == 0) { tc_node[n_tc] = node; tc_val[n_tc] = v; d.child_off[nb + node] = term_code(v); }
                 n_tc += 1;
+                if (len == 2 && root_child >= 0) {
+#pragma unroll
+                    for (int k = 0; k < CPL; ++k)
+                        if (lane + 64 * k == root_child) { rc.cf[k] = term_code(v); pk[k] = rc.packed(k); }
+                }
             }
             if (lane == 0) d.term_value[gs] = v;
             ref = -1;
@@ -848,11 +911,11 @@ __device__ __forceinline__ void select_body(const Dev& d, int batch_n, RootCache
             last_node = node; last_ref = ref;
         }
         const int n1 = len > 1 ? (root_child >= 0 ? rfirst + root_child : path_lds[1]) : -1;   // the root child on the path
-        if (lane == 0) { st_len[slot] = len; st_ref[slot] = ref; st_n1[slot] = n1; st_leaf[slot] = node; }
+        put_record(slot, len, ref, n1, node);
+        if (root_child >= 0) guess = root_child;
         depth_sum += len - 1;
         max_depth = max(max_depth, len - 1);
         wave_sync();
-        if (slot == 1) ESTAMP(10);
         if (d.vl > 0.0) {  // mcts.py:196-199
             if (cached) {
                 rc.r_vis += 1;
@@ -871,22 +934,22 @@ __device__ __forceinline__ void select_body(const Dev& d, int batch_n, RootCache
             }
         }
         wave_sync();
-        if (slot == 1) { ESTAMP(11); ESTAMP_CYCLES(13); }
     }
     ESTAMP(5);
     // the batch's results: the record for the expansion, the path lengths and slot tables the leaf gather reads
     int* brec = d.brec + (size_t)g * brec_words(d);
     for (int sl = lane; sl < batch_n; sl += 64) {
-        const int len = st_len[sl];
+        const int len = sl < 64 ? my_len : st_len[sl], ref = sl < 64 ? my_ref : st_ref[sl];
+        const int n1 = sl < 64 ? my_n1 : st_n1[sl], leaf = sl < 64 ? my_leaf : st_leaf[sl];
         d.path_len[g * d.B + sl] = len;
-        d.leaf_ref[g * d.B + sl] = st_ref[sl];
-        brec[4 + sl] = len | ((st_ref[sl] + 1) << 16);
-        brec[4 + d.B + sl] = st_n1[sl];
-        brec[4 + 2 * d.B + sl] = st_leaf[sl];
-        if (len <= PSTAGE) {
-            int* path = d.path + ((size_t)g * d.B + sl) * d.max_depth;
+        d.leaf_ref[g * d.B + sl] = ref;
+        brec[4 + sl] = len | ((ref + 1) << 16);
+        brec[4 + d.B + sl] = n1;
+        brec[4 + 2 * d.B + sl] = leaf;
+        int* path = d.path + ((size_t)g * d.B + sl) * d.max_depth;
+        if (len == 2) { path[0] = 0; path[1] = leaf; }
+        else if (len <= PSTAGE)
             for (int i = 0; i < len; ++i) path[i] = st_path[sl * PSTAGE + i];
-        }
     }
     for (int u = lane; u < n_unique; u += 64) { d.uniq_slot[g * d.B + u] = uniq_lds[2 * u]; brec[4 + 3 * d.B + u] = uniq_lds[2 * u]; }
     int row0 = 0;
@@ -1021,9 +1084,10 @@ __device__ inline double pw_sum_wave(const double* a, int n, int lane) {
 // mcts.py:66-91 + :118-137 for one node: masked softmax (float64), optional noise, top-k, children.
 // p_lds: double[2*A] work arrays (probabilities, ranking keys); runs on the whole wave. PPA: actions per lane, A <= 64 PPA.
 // Returns the number of children the node received, or -1 when it had children already or the node pool is full.
+// first_out (may be null): index of the first child created.
 template <int PPA>
 __device__ inline int expand_node(const Dev& d, int g, int lane, int node, const float* logits, const uint8_t* legal,
-                                  const double* noise, double* p_lds, double* priors_out) {
+                                  const double* noise, double* p_lds, double* priors_out, int* first_out = nullptr) {
     const int A = d.A;
     double* q_lds = p_lds + A;
     bool lg_[PPA];
@@ -1191,6 +1255,7 @@ __device__ inline int expand_node(const Dev& d, int g, int lane, int node, const
     }
     __threadfence_block();
     __syncthreads();
+    if (first_out) *first_out = first;
     return already ? -1 : cnt;
 }
 
@@ -1256,14 +1321,15 @@ __device__ __forceinline__ void expand_backup_body(const Dev& d, const float* lo
     for (int u = 0; u < nu; ++u) {
         const int slot = r_uniq[u];
         const int plen = r_len[slot] & 0xffff, node = r_leaf[slot];
+        int first_new = 0;
         const int made = expand_node<CPL>(d, g, lane, node, logits + (size_t)(r0 + u) * d.A, d.row_legal + (size_t)(r0 + u) * d.A, nullptr, p_lds,
-                                          priors_out ? priors_out + (size_t)(r0 + u) * d.A : nullptr);
+                                          priors_out ? priors_out + (size_t)(r0 + u) * d.A : nullptr, &first_new);
         if (plen == 2) {   // a child of the root
             const int ci = node - rfirst;
             if (made >= 0 && cached) {
 #pragma unroll
                 for (int k = 0; k < CPL; ++k)
-                    if (lane + 64 * k == ci) rc.nch[k] = made;
+                    if (lane + 64 * k == ci) { rc.nch[k] = made; rc.cf[k] = first_new; }
             }
             if (d.rc_cap && ci >= 0 && ci < d.rc_cap) {   // a candidate for the next root: keep its evaluation
                 float* dst = d.rc_logits + ((size_t)g * d.rc_cap + ci) * d.A;

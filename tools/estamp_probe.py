@@ -20,7 +20,7 @@ cfg = SelfPlayConfig(board_size=9, mcts_simulations=192, mcts_inference_batch=ba
 sp = BatchedSelfPlay(net, cfg, games=games, seed0=1, lanes=1)
 sp.begin(num_games=10 ** 9)
 names = ["record", "values + root loads", "expand", "backup", "descents", "record out", "rows + stats", "store"]
-for move in (1, 20, 40):
+for move in (1, 40, 80, 110):
     while sp.counters["steps"] < move:
         sp.step()
     n = min(games, 4096)
@@ -31,11 +31,16 @@ for move in (1, 20, 40):
     dt = np.diff(t, axis=1) / 100.0
     tot = (t[:, 7] - t[:, 0]) / 100.0
     print(f"move {move}: total mean {tot.mean():.1f} us, max {tot.max():.1f} us")
+    ok = t[:, 7] > 0
+    print(f"   waves above 1.5x the median total: {int((tot[ok] > 1.5 * np.median(tot[ok])).sum())} of {int(ok.sum())}; p50 {np.median(tot[ok]):.1f} p90 {np.percentile(tot[ok], 90):.1f} p99 {np.percentile(tot[ok], 99):.1f}")
     for i, nm in enumerate(names[:7]):
-        print(f"   {nm:22s} mean {dt[:, i].mean():6.2f}  max {dt[:, i].max():6.2f}")
-    f = buf.reshape(n, 16)[:, 8:14].astype(np.int64)
-    if f[:, 0].any():     # the second descent of the batch in detail, and the shader clock over it
-        d2 = np.diff(f[:, :4], axis=1) / 100.0
-        clk = (f[:, 5] - f[:, 4]) / np.maximum(1, f[:, 3] - f[:, 0]) * 100.0
-        print(f"   descent 2: child choice {d2[:, 0].mean():5.2f}  leaf bookkeeping {d2[:, 1].mean():5.2f}  virtual loss {d2[:, 2].mean():5.2f} us; "
-              f"shader clock {np.median(clk):.0f} MHz")
+        if i in (0, 3):
+            continue      # stamps 1-3 come from the final k_expand_backup launch: the differences across them mean nothing
+        print(f"   {nm:22s} mean {dt[ok, i].mean():6.2f}  p90 {np.percentile(dt[ok, i], 90):6.2f}  max {dt[ok, i].max():6.2f}")
+    f = buf.reshape(n, 16)[:, 8:16].astype(np.int64)
+    okf = (f > 0).all(axis=1)
+    if okf.any():     # shader cycles from the start of one descent to the start of the next, first eight descents of the batch
+        d2 = np.diff(f[okf], axis=1)
+        print("   descents 1-7, median shader cycles each: " + " ".join(str(int(np.median(d2[:, i]))) for i in range(7))
+              + "; p90: " + " ".join(str(int(np.percentile(d2[:, i], 90))) for i in range(7)))
+        print(f"   start of the descents after the kernel's first stamp: {np.median((t[okf, 4] - t[okf, 0]) / 100.0):.2f} us (real time)")
