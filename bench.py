@@ -214,6 +214,68 @@ def kernel_census(net, batch, games, plies=24):
     return out, {"games": games, "root_plies": plies, "mean_leaf_depth": round(depth, 3), "rounds": n_rounds}
 
 
+def train_step_leg(net, dev, dist, world, host_staged, batch=256, steps=20, warmup=3):
+    """The data-parallel training step of BASELINE.json configs[3] (go_zero/train.py:504-554: AdamW, cosine LR, AMP, clip 1.0)
+    under the benchmark's own process group: batch 256 per GPU of the 192ch x 12 network on synthetic replay samples assembled
+    by az_replay_gather, gradients averaged by one flat all-reduce. Returns ms per step (slowest rank), the all-reduce alone
+    and samples/s over all ranks. Every rank must call it (it runs collectives)."""
+    import copy
+    import numpy as np
+    import torch
+    from alphazero_amd import train as T
+    from alphazero_amd.train_step import DataParallelTrainer, all_reduce_
+    model = copy.deepcopy(net).to(dev)
+    rng = np.random.RandomState(17)
+    samples = []
+    for _ in range(2048):
+        st = (rng.rand(21, 9, 9) < 0.3).astype(np.float32)
+        st[-2:] = 0.0
+        samples.append((st, rng.dirichlet([0.5] * 82).astype(np.float32), float(rng.choice([-1.0, 1.0])), 0.5))
+    buf = T.ReplayBuffer(8192)
+    buf.extend(samples)
+    buf.attach_device(dev, 9, 8)
+    trainer = DataParallelTrainer(model, lr=1e-3, total_steps=steps + warmup, use_amp=True)
+    np.random.seed(5); import random as _r; _r.seed(5)
+
+    def one():
+        states, pis, zs = buf.sample_device(batch, 9, True)
+        return trainer.step(states, pis, zs)
+
+    for _ in range(warmup):
+        one()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = one()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ar_ms = None
+    if dist is not None and trainer._flat is not None:     # the collective alone, on the gradient buffer of the last step
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(10):
+            all_reduce_(dist, trainer._flat)
+        torch.cuda.synchronize()
+        ar_ms = (time.perf_counter() - t1) / 10 * 1e3
+    t = torch.tensor([dt], dtype=torch.float64, device="cpu" if host_staged else dev)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t[0])
+    params = sum(p.numel() for p in model.parameters())
+    del trainer, model, buf
+    torch.cuda.empty_cache()
+    return {"ms_per_step": round(dt / steps * 1e3, 3), "allreduce_ms": None if ar_ms is None else round(ar_ms, 3),
+            "samples_per_s": round(world * batch * steps / dt, 1), "batch_per_gpu": batch, "steps": steps, "amp": True,
+            "gradient_bytes": params * 4, "last_loss": round(float(loss[0]), 4),
+            "what": "DataParallelTrainer.step on the 192ch x 12 network (upstream train_candidate's step, train.py:504-554), batches "
+                    "assembled on the device by az_replay_gather, one flat all-reduce of the gradients per step over the process group "
+                    "(RCCL; host-staged gloo in the one-GPU rehearsal); the forward/backward is PyTorch's"}
+
+
 class PowerWatch:
     """Socket power and XCD clocks of the card (amd-smi, a sample every ~0.25 s from a side thread) while the timed window runs;
     silent when the tool is missing or refuses. The figures say whether the run sits at the card's power limit."""
@@ -301,7 +363,8 @@ def main():
     ap.add_argument("--sync-search", action="store_true", help="one host round trip per inference batch instead of enqueueing a move's batches back to back (A/B timing)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="search time per CPU-baseline leg")
-    ap.add_argument("--no-side-legs", action="store_true", help="skip the no-dedup window, the kernel census and the plies-per-game run")
+    ap.add_argument("--no-side-legs", action="store_true", help="skip the no-dedup window, the kernel census, the plies-per-game run and the training-step leg")
+    ap.add_argument("--no-train-step", action="store_true", help="skip the data-parallel training-step leg")
     ap.add_argument("--force-dist", action="store_true", help="N=1: still go through a one-rank RCCL process group")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="test only: all ranks share GPU 0 and synchronise over gloo with host tensors (RCCL refuses two ranks on one "
@@ -377,17 +440,40 @@ def main():
                          tower_workgroups=twg)
     if a.sync_search:
         sp.set_async(False)
-    with PowerWatch(local) as pw:
+    # device identity check: N ranks must sit on N different GPUs (a launcher that hands two ranks the same card would report
+    # a "scaling" figure from time-sliced devices)
+    if dist is not None and world > 1 and not a.rehearse_on_one_gpu:
+        props = torch.cuda.get_device_properties(local)
+        ident = f"{socket.gethostname()}:{getattr(props, 'uuid', None) or getattr(props, 'pci_bus_id', local)}:{local}"
+        idents = [None] * world
+        dist.all_gather_object(idents, ident)
+        if len(set(idents)) != world:
+            raise SystemExit(f"bench.py --gpus {world}: ranks share a device ({idents})")
+
+    class _NoWatch:          # ranks other than 0 do not sample the power: one sampler per node is enough
+        def __enter__(self): return self
+        def __exit__(self, *exc): return False
+        def summary(self): return None
+        t0 = t1 = None
+
+    with (PowerWatch(local) if rank == 0 else _NoWatch()) as pw:
         dt, (tower_ms_sum, launches, tower_ms) = window(sp, a.steps, a.warmup, watch=pw)   # tower_ms: merged (overlap counted once)
 
     c = dict(sp.counters)
     mine = torch.tensor([dt, c["sims"], c["nn_rows"], c["nn_rows_nodedup"], c["moves"], c["games"], c["depth_sum"]],
                         dtype=torch.float64, device="cpu" if a.rehearse_on_one_gpu else dev)
+    rank_rates = [c["sims"] / dt]
+    train_leg = None
+    if headline and not a.no_side_legs and not a.no_train_step:
+        train_leg = train_step_leg(net, dev, dist, world, a.rehearse_on_one_gpu)     # collective: every rank takes part
     if dist is not None:
         tmax = mine[:1].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tot = mine.clone()
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        rates = [torch.zeros(1, dtype=torch.float64, device=mine.device) for _ in range(world)]
+        dist.all_gather(rates, torch.tensor([c["sims"] / dt], dtype=torch.float64, device=mine.device))
+        rank_rates = [float(r[0]) for r in rates]
         dt_max, tot = float(tmax[0]), tot.cpu().tolist()
         # the collectives end here, for every rank: what follows (side legs, CPU baseline) is rank 0's alone, and a
         # barrier inside it would have no partner
@@ -437,9 +523,28 @@ def main():
                      "rows_per_launch": round(tower_rows / max(1, launches), 1), "flop_per_position": fl_pos,
                      "tower_share_of_wall": round(tower_ms * 1e-3 / dt, 4)},
         "host_seconds": {"rng": round(c["t_host_rng"], 4), "policy": round(c["t_host_policy"], 4), "samples": round(c["t_samples"], 4)},
+        "per_rank_sims_per_s": {"min": round(min(rank_rates), 1), "max": round(max(rank_rates), 1),
+                                "note": "each rank's own simulations / its own wall time over the timed steps; value uses the slowest rank's time"},
     }
+    if train_leg is not None:
+        out["train_step"] = train_leg
+    if a.steps >= 300:      # a window of several game lengths: finished games counted, not derived
+        out["games_per_hour_counted"] = round(games / dt_max * 3600, 1)
+        out["games_per_hour_counted_note"] = f"{int(games)} games finished in the {dt_max:.1f} s window (slots refill as games end; the window starts from running games)"
     if pw.summary():
         out["power"] = pw.summary()
+    if not headline and world == 1 and not a.no_side_legs:
+        # small networks: the two HIP events around every tower launch cost a visible share of a move; the same window again
+        # without them (no roofline figures from this one)
+        for k in sp.counters:
+            sp.counters[k] = 0
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            sp.step()
+        torch.cuda.synchronize()
+        dt3 = time.perf_counter() - t0
+        out["without_launch_timing"] = {"ms_per_step": round(dt3 / a.steps * 1e3, 3), "sims_per_s": round(sp.counters["sims"] / dt3, 1)}
     del sp
     if not a.no_side_legs and headline:
         # games/hour: moves/s of the timed window over the plies a finished game takes, measured on whole games of the same
@@ -451,9 +556,9 @@ def main():
                                       "in this run with the same network and search settings (256 lockstep slots, untimed)")
         if not a.no_dedup:   # the like-for-like figure for upstream's every-leaf evaluation: a short window of its own
             sp2 = BatchedSelfPlay(net, cfg, games=a.games, seed0=1 + rank * a.games, dedup_leaves=False, lanes=a.lanes, tower_workgroups=twg)
-            dt2, _ = window(sp2, 2, 1, setup=1)
+            dt2, _ = window(sp2, 5, 1, setup=1)
             out["value_no_dedup"] = round(sp2.counters["sims"] / dt2, 1)
-            out["value_no_dedup_note"] = (f"sims/s of this rank over 2 steps with every leaf evaluated ({sp2.counters['nn_rows']} network rows for "
+            out["value_no_dedup_note"] = (f"sims/s of this rank over 5 steps with every leaf evaluated ({sp2.counters['nn_rows']} network rows for "
                                           f"{sp2.counters['sims']} simulations), as upstream does")
             del sp2
         out["roofline_other"], out["roofline_other_setup"] = kernel_census(net, a.batch, a.games)

@@ -307,3 +307,9 @@ def test_bench_two_rank_control_flow():
     # 2 ranks x 128 games x 256 simulations per step
     assert abs(d["value"] * d["ms_per_step"] * 1e-3 / (2 * 128 * 256) - 1.0) < 1e-3   # the printed figures are rounded
     assert d["value_no_dedup"] > 0 and len(d["roofline_other"]) == 3 and d["games_per_hour"] > 0
+    # the data-parallel training step ran under the same process group (both ranks), with its all-reduce timed alone
+    ts = d["train_step"]
+    assert ts["ms_per_step"] > 0 and ts["allreduce_ms"] > 0 and ts["batch_per_gpu"] == 256 and ts["gradient_bytes"] == 4 * 9149627
+    assert ts["samples_per_s"] == pytest.approx(2 * 256 / (ts["ms_per_step"] * 1e-3), rel=1e-2)
+    pr = d["per_rank_sims_per_s"]
+    assert 0 < pr["min"] <= pr["max"] and pr["min"] * 2 <= d["value"] * 1.001 <= pr["max"] * 2 * 1.001 + 1e-9 or pr["min"] > 0
