@@ -25,6 +25,7 @@ NATIVE_ROUNDS = os.environ.get("AZ_NATIVE_ROUNDS", "1") != "0"   # 0: one call p
 # 0: the per-move host half (policy targets, move sampling, resignation, play, status) in NumPy with a device round trip per
 # piece, as before the native lane (az_lane_*) existed; same games either way (A/B timing and cross-check)
 NATIVE_LANE = os.environ.get("AZ_NATIVE_LANE", "1") != "0"
+_LANE_DELAY = float(os.environ.get("AZ_LANE_DELAY_MS", "0")) * 1e-3     # experiment: host pause between a lane's moves
 
 
 @dataclass
@@ -412,6 +413,8 @@ class _Lane:
                     N.check(N.lib().az_lane_prepare(self.nl, self._stream_ptr()), "az_lane_prepare")
         c["t_host_policy"] += time.perf_counter() - t0
         self.step_no += 1
+        if _LANE_DELAY > 0:
+            time.sleep(_LANE_DELAY)
 
     def finish(self):
         if self.inflight is None:

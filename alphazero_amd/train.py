@@ -65,7 +65,7 @@ _SPEC = [
 # Knobs of the GPU engine that upstream has no counterpart for (kept out of upstream's field set on purpose).
 _ENGINE_SPEC = [
     ("lockstep_games", 0, "value"),      # device game slots per GPU (0: as many as the iteration has games, at most 4096)
-    ("selfplay_lanes", 0, "value"),      # independent lanes (0: 4 from 2048 game slots, 3 from 768, 2 from 512, else 1)
+    ("selfplay_lanes", 0, "value"),      # independent lanes (0: 2 from 256 game slots on, else 1)
     ("no_dedup_leaves", False, "flag"),  # evaluate a leaf reached by several descents of a batch every time, as upstream does
 ]
 UPSTREAM_FIELDS = tuple(n for n, _, _ in _SPEC)
@@ -419,11 +419,12 @@ def run_selfplay(best_model, cfg, iter_idx: int, pool=None, model_path=None, mod
     best_model.eval()
     on_gpu = next(best_model.parameters()).is_cuda
     slots = min(mine, cfg.lockstep_games if cfg.lockstep_games > 0 else 4096)
-    # measured on the 192ch x 12 network (ms per lockstep move, lanes 1/2/3/4): 512 games 12.1/13.5/-/-, 768 games 17.7/15.0/15.7/-,
-    # 1024 games 20.3/17.6/18.9/18.7, 2048 games -/33.8/-/33.5, 4096 games: 4 lanes; a light network (64ch x 4) is bound by the
-    # host half of a move, which a second lane hides from 512 games on
-    light = cfg.channels * cfg.num_blocks <= 512
-    lanes = cfg.selfplay_lanes if cfg.selfplay_lanes > 0 else (4 if slots >= 2048 else 2 if slots >= 768 or (light and slots >= 512) else 1)
+    # With a move's host half on the device (az_lane_*) a lane needs no partner to hide it: two lanes from 256 games on, so that
+    # one lane's rules / search kernels run under the other's network, and never more (measured on the 192ch x 12 network, ms per
+    # lockstep move over a whole game span, lanes 1 / 2: 256 games 10.8 / 10.3, 512 games 16.7 / 14.1, 1024 games 26.6 / 20.7, 2048
+    # games 44.5 / 38.3 and 43.4 with four; 64ch x 4: 512 games 2.16 / 1.98, 1024 games 3.30 / 2.55; 4096 games of the headline
+    # bench: 15.6 M sims/s with two lanes, 15.1 M with four, whose concurrent tower launches evict each other's weights)
+    lanes = cfg.selfplay_lanes if cfg.selfplay_lanes > 0 else (2 if slots >= 256 else 1)
     sp = BatchedSelfPlay(best_model if on_gpu else _host_evaluator(best_model), SelfPlayConfig.from_train_config(cfg), games=slots,
                          seed0=selfplay_seed0(cfg, iter_idx) + first, dedup_leaves=not cfg.no_dedup_leaves, lanes=lanes,
                          tower_workgroups=1024 if lanes > 1 else None)

@@ -35,7 +35,7 @@ SIMS, TOPK, VLOSS, CH, BLOCKS = 256, 48, 1.0, 192, 12       # the headline workl
 # --config N selects one of BASELINE.json's other GPU configurations (1-based, as the survey numbers them); they are
 # parity-test shapes whose lines are kept under profiles/, not the headline
 WORKLOADS = {
-    3: dict(board=9, ch=192, blocks=12, sims=256, topk=48, games=4096, lanes=4, batch=16,
+    3: dict(board=9, ch=192, blocks=12, sims=256, topk=48, games=4096, lanes=2, batch=16,
             text="9x9 full net 192ch x 12 SE blocks, 256 sims/move, top-k 48, virtual loss 1.0, {g} lockstep games per GPU (BASELINE.json configs[2])"),
     2: dict(board=9, ch=64, blocks=4, sims=192, topk=0, games=512, lanes=2, batch=16,
             text="9x9 small net 64ch x 4 blocks, 192 sims/move, {g} lockstep games per GPU (BASELINE.json configs[1])"),
