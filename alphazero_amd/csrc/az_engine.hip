@@ -19,6 +19,7 @@
 
 #include "../../include/azamd.h"
 #include "az_board.cuh"
+#include "az_net.h"
 
 namespace az {
 
@@ -1026,11 +1027,12 @@ __global__ __launch_bounds__(64) void k_leaf(Dev d, void* out, int layout, const
     if (slot < 0 && lane == 0) d.root_count[g] = n_legal;
 }
 
-// numpy pairwise summation of a contiguous float64 vector (ndarray.sum(), mcts.py:80), n <= 512, by the whole wave with
+// numpy pairwise summation of a contiguous float64 vector (ndarray.sum(), mcts.py:80), n <= 504 (two levels of halving; the
+// engine has n <= 362, checked in az_engine_create), by the whole wave with
 // numpy's own addition tree. numpy splits n > 128 in halves (the first rounded down to a multiple of 8) until a piece has
 // at most 128 elements, and sums a piece with eight interleaved accumulators r_j = a[j] + a[8+j] + a[16+j] + ... that
 // are combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), then adds the piece's last n%8 elements one by one. Here lane
-// 8b+j owns accumulator j of piece b (at most 4 pieces for n <= 512), the combination is the xor-1/2/4 butterfly (the
+// 8b+j owns accumulator j of piece b (at most 4 pieces), the combination is the xor-1/2/4 butterfly (the
 // same tree: float addition commutes), and the pieces are added in numpy's order. Every lane returns the sum.
 __device__ inline double pw_sum_wave(const double* a, int n, int lane) {
     if (n < 8) {   // wave-uniform
@@ -1479,7 +1481,7 @@ struct az_engine {
     std::vector<void*> allocs;
     // az_mcts_run_rounds: the launches of all remaining batch rounds of a search, captured once and replayed per move
     hipGraphExec_t rounds_exec = nullptr;
-    const void* rounds_key[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // net, features, logits, values, (layout, first batch)
+    const void* rounds_key[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // net, features, logits, values, (layout, first batch), net generation
 };
 
 #define DISPATCH_PPL(e, KERNEL, grid, shmem, stream, ...)                                              \
@@ -1530,6 +1532,10 @@ int az_engine_create(const az_config* c, az_engine** out) {
     d.dedup = c->dedup_leaves ? 1 : 0;
     d.komi = c->komi; d.eps = c->dirichlet_eps; d.one_minus_eps = 1 - c->dirichlet_eps;
     e->ppl = d.np <= 64 ? 1 : d.np <= 128 ? 2 : d.np <= 192 ? 3 : 6;
+    {   // what the search kernels are laid out for: actions per lane (Apl), the pairwise-sum pieces, the packed child word
+        const int apl = e->ppl <= 2 ? 2 : e->ppl;
+        if (d.A > 64 * apl || d.A > 504 || d.A > 1023) { delete e; return fail(AZ_ERR_ARG, "action count above the search kernels' layout"); }
+    }
     d.npad = 64 * e->ppl;
     d.seen_cap = 2 * d.np + 2;
     const int kc = d.K > 0 ? std::min(d.K, d.A) : d.A;
@@ -1861,7 +1867,10 @@ int az_mcts_run_rounds(az_engine* e, az_net* net, void* feat, int32_t layout, fl
     if (!use_graph || !stream || !az_net_capturable(net, max_rows)) return enqueue_rounds(e, net, feat, layout, logits, values, stream);
     // One graph per (network, buffers, layout, simulations already done): the launch arguments of a move's rounds never
     // change - row counts live on the device - so later moves replay it.
-    const void* key[5] = {net, feat, logits, values, (const void*)(uintptr_t)(((uint64_t)(uint32_t)layout << 32) | (uint32_t)e->sims_done)};
+    // ... and state of the network (a reload frees the weights the captured launches point at, a new workgroup limit or
+    // scratch changes their arguments): net_generation
+    const void* key[6] = {net, feat, logits, values, (const void*)(uintptr_t)(((uint64_t)(uint32_t)layout << 32) | (uint32_t)e->sims_done),
+                          (const void*)(uintptr_t)net_generation(net)};
     if (!e->rounds_exec || memcmp(key, e->rounds_key, sizeof(key)) != 0) {
         if (e->rounds_exec) { (void)hipGraphExecDestroy(e->rounds_exec); e->rounds_exec = nullptr; }
         const int phase0 = e->phase, sims0 = e->sims_done;

@@ -34,6 +34,11 @@ int layers_cap_boards(const LayerNet* m);
 int layers_reserve(LayerNet* m, int boards);
 int layers_tower(LayerNet* m, const uint16_t* feat, int boards, uint16_t* hq, hipStream_t st, const int* rows_dev = nullptr, int board_off = 0);
 
+// Changes whenever something a captured launch sequence of the network depends on changes: weights and scratch pointers
+// (az_net_load, az_net_reserve), launch shape (az_net_set_tower_workgroups, az_net_set_device_choice). A HIP graph recorded
+// over az_net_forward_indirect is stale once this differs from its value at capture.
+unsigned long long net_generation(const az_net* net);
+
 // bf16 MFMA path (az_net_mfma.hip)
 struct MfmaNet;
 bool mfma_supported(const az_net_config& c);

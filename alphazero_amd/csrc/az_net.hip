@@ -164,7 +164,12 @@ struct az_net {
     float *x = nullptr, *h = nullptr, *y = nullptr, *scale = nullptr, *p0 = nullptr, *p1 = nullptr, *v0 = nullptr, *v1 = nullptr;
     // bf16 MFMA path
     MfmaNet* mfma = nullptr;
+    unsigned long long generation = 1;   // see net_generation
 };
+
+namespace az {
+unsigned long long net_generation(const az_net* net) { return net ? net->generation : 0; }
+}
 
 static int upload(az_net* net, const std::vector<float>& v, float** out) {
     void* p = nullptr;
@@ -214,6 +219,7 @@ int az_net_load(az_net* net, const float* P, int64_t count) {
     if (!net || !P) return fail(AZ_ERR_ARG, "null argument");
     if (count != net->L.total) return fail(AZ_ERR_ARG, "parameter blob has the wrong length");
     HIP_TRY(hipSetDevice(net->cfg.device));
+    net->generation += 1;
     const az_net_config& c = net->cfg;
     const NetLayout& L = net->L;
     const int C = c.channels, np = c.board_size * c.board_size, q = C / 4;
@@ -293,12 +299,14 @@ int az_net_profile_spans(az_net* net, double* spans_ms, int64_t capacity, int64_
 int az_net_set_tower_workgroups(az_net* net, int32_t workgroups) {
     if (!net) return fail(AZ_ERR_ARG, "null network");
     if (net->cfg.precision != AZ_NET_BF16 || !net->mfma) return fail(AZ_ERR_STATE, "az_net_set_tower_workgroups: bf16 network not loaded");
+    net->generation += 1;
     return mfma_set_grid_limit(net->mfma, workgroups);
 }
 
 int az_net_set_device_choice(az_net* net, int32_t on) {
     if (!net) return fail(AZ_ERR_ARG, "null network");
     if (net->cfg.precision != AZ_NET_BF16 || !net->mfma) return fail(AZ_ERR_STATE, "az_net_set_device_choice: bf16 network not loaded");
+    net->generation += 1;
     mfma_set_device_choice(net->mfma, on != 0);
     return AZ_OK;
 }
@@ -330,6 +338,7 @@ int az_net_reserve(az_net* net, int32_t rows) {
     if (!net) return fail(AZ_ERR_ARG, "null network");
     if (!net->loaded) return fail(AZ_ERR_STATE, "az_net_reserve before az_net_load");
     if (rows < 1) return fail(AZ_ERR_ARG, "az_net_reserve: rows must be >= 1");
+    net->generation += 1;
     if (net->cfg.precision == AZ_NET_BF16) return mfma_reserve(net->mfma, rows);
     HIP_TRY(hipSetDevice(net->cfg.device));
     return ensure_scratch(net, rows);

@@ -1284,8 +1284,8 @@ static int prof_begin(MfmaNet* m, long long rows, hipStream_t st, std::pair<hipE
 
 // Fused tower + tails with the given scratch (head activations for `rows` rows, residual stream for `grid_cap` workgroups).
 static int fused_forward(MfmaNet* m, const void* feat, int rows, const int* rows_dev, float* logits, float* values, hipStream_t st,
-                         uint16_t* hq, uint4* xres, int grid_cap, bool timed) {
-    const bool static_scratch_call = !timed;   // the static scratch array is laid out for the 256-row kernel
+                         uint16_t* hq, uint4* xres, int grid_cap, bool timed, bool static_scratch_call) {
+    // static_scratch_call: the scratch is the library's static array, laid out for the 256-row kernel and kStaticGrid workgroups
     const az_net_config& c = m->cfg;
     const int C = c.channels;
     TowerParams P;
@@ -1424,14 +1424,14 @@ static int fused_forward(MfmaNet* m, const void* feat, int rows, const int* rows
 // each pass past the live rows costs its launches of workgroups that leave at once).
 int mfma_indirect_passes(const MfmaNet* m, int max_rows) {
     if (!m->layers) return 1;
-    const int cap = layers_cap_boards(m->layers);
+    const int cap = std::max(1, std::min(layers_cap_boards(m->layers), m->hq_rows));
     return (max_rows + cap - 1) / cap;
 }
 
 // Whether an indirect forward over `max_rows` rows consists of kernel launches only, with nothing that a stream capture
 // could not record: one pass, scratch already reserved (no allocation), launch timing off (its events are per launch).
 bool mfma_capturable(const MfmaNet* m, int max_rows) {
-    return !m->profiling && mfma_indirect_passes(m, max_rows) == 1 && (m->layers ? true : max_rows <= m->hq_rows);
+    return !m->profiling && mfma_indirect_passes(m, max_rows) == 1 && max_rows <= m->hq_rows;
 }
 
 // rows_dev == null: `rows` positions. rows_dev != null: *rows_dev positions (read on the device, at most `rows`).
@@ -1445,7 +1445,11 @@ int mfma_forward(MfmaNet* m, const void* feat, int rows, const int* rows_dev, fl
         if (rcp != AZ_OK) return rcp;
         // direct: even shares, no small last chunk. indirect: whole chunks over the upper bound; the workgroups of a chunk
         // past the device-side count leave at once, so a batch that fills one chunk pays for the others' empty launches only
-        const int nchunks = (rows + chunk - 1) / chunk, per = rows_dev ? layers_cap_boards(m->layers) : (rows + nchunks - 1) / nchunks;
+        // (a pass never exceeds what the head scratch holds: a failed allocation in mfma_reserve may have left the activation
+        // arrays larger than it)
+        const int nchunks = (rows + chunk - 1) / chunk;
+        const int per = std::min(m->hq_rows, rows_dev ? layers_cap_boards(m->layers) : (rows + nchunks - 1) / nchunks);
+        if (per < 1) return fail(AZ_ERR_STATE, "bf16 forward (layers): no head scratch");
         for (int off = 0; off < rows; off += per) {
             const int nb = std::min(per, rows - off);
             int rc = layers_tower(m->layers, (const uint16_t*)feat + (size_t)off * np * 32, nb, m->hq, st, rows_dev, off);
@@ -1461,7 +1465,7 @@ int mfma_forward(MfmaNet* m, const void* feat, int rows, const int* rows_dev, fl
         int rc = mfma_reserve(m, rows + rows / 4 + 16);
         if (rc != AZ_OK) return rc;
     }
-    return fused_forward(m, feat, rows, rows_dev, logits, values, st, m->hq, m->xres, m->max_grid, true);
+    return fused_forward(m, feat, rows, rows_dev, logits, values, st, m->hq, m->xres, m->max_grid, true, false);
 }
 
 // ---- the entry point that allocates nothing: scratch in a device array of the library itself -----------------------
@@ -1505,7 +1509,7 @@ int mfma_forward_static(MfmaNet* m, const void* feat, int rows, float* logits, f
     unsigned char* base = nullptr;
     int rc = static_scratch(m->cfg.device, &base);
     if (rc != AZ_OK) return rc;
-    return fused_forward(m, feat, rows, nullptr, logits, values, st, (uint16_t*)(base + static_xres_bytes(m)), (uint4*)base, kStaticGrid, false);
+    return fused_forward(m, feat, rows, nullptr, logits, values, st, (uint16_t*)(base + static_xres_bytes(m)), (uint4*)base, kStaticGrid, false, true);
 }
 
 }  // namespace az

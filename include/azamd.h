@@ -126,7 +126,8 @@ int az_mcts_set_async(az_engine* e, int32_t enable);
  * rounds are enqueued one by one. Returns 1 when the graph was launched, 0 when the rounds were enqueued, < 0 on error.
  * Failures of the rounds themselves surface at az_mcts_stats, as in asynchronous mode. A captured graph refers to the
  * network's weights and scratch buffers: keep the network alive as long as the engine may replay it (az_engine_destroy and
- * az_mcts_set_root_reuse drop the graph). */
+ * az_mcts_set_root_reuse drop the graph). az_net_load, az_net_reserve, az_net_set_tower_workgroups and
+ * az_net_set_device_choice on that network make the next call capture anew instead of replaying. */
 int az_mcts_run_rounds(az_engine* e, az_net* net, void* feat_dev, int32_t layout, float* logits_dev, float* values_dev,
                        int32_t use_graph, void* stream);
 /* Device address of the int32 pending-row count (valid on `stream` after az_mcts_begin/az_mcts_select),
@@ -182,8 +183,9 @@ int az_net_forward(az_net* net, const void* feat_dev, int32_t rows, float* logit
  * as the lazily built torch workspace behind model(x) in mcts.py:59-64. */
 int az_net_reserve(az_net* net, int32_t rows);
 
-/* *fused = 1 if the bf16 network runs as the single fused tower kernel (boards up to 9x9 with up to 192 channels; 11x11 to 13x13 with 192 channels; 17x17 to 19x19 with 128 channels), 0 if
- * it runs layer by layer (larger boards, 256 channels) or in float32. */
+/* *fused = 1 if the bf16 network runs as the single fused tower kernel (boards up to 9x9 with 32, 64, 128 or 192 channels;
+ * 11x11 to 16x16 with 128 or 192 channels; 17x17 to 19x19 with 128 channels), 0 if it runs layer by layer (the other shapes,
+ * every 256-channel tower) or in float32. */
 int az_net_is_fused(az_net* net, int32_t* fused);
 /* az_net_forward with the row count read on the device from *rows_dev (<= max_rows): no host round trip. bf16
  * networks of either kind; a layer-by-layer network runs whole chunks over max_rows whose surplus workgroups exit. */
@@ -193,7 +195,7 @@ int az_net_forward_indirect(az_net* net, const void* feat_dev, const int32_t* ro
  * loops, harnesses that forbid hipMalloc): no counterpart upstream. Fused bf16 networks on boards up to 9x9 only (az_net_static_max_rows is 0
  * for the others). The activation
  * scratch is a 64 MiB device array inside the library (one copy per GPU, held until the process ends): residual
- * stream for 256 workgroups, then the head activations, which bounds `rows` by az_net_static_max_rows (2 697 rows
+ * stream for 256 workgroups, then the head activations, which bounds `rows` by az_net_static_max_rows (2 696 rows
  * for 9x9 / 192 channels); more rows return AZ_ERR_CAPACITY. The call allocates and frees nothing and records no
  * events. Every network and every call on a GPU shares that GPU's array: calls that overlap on one GPU (other
  * streams or threads) race; calls on one stream are ordered and safe. Results equal az_net_forward's bit for bit. */

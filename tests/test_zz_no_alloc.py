@@ -1,7 +1,7 @@
 """az_net_forward_static: the bf16 forward whose activation scratch is a device array inside the library, so the call
 allocates nothing. Through the C ABI, against az_net_forward on the same inputs: bit-equal outputs on two calls in a
-row, the second with fewer rows (the shared scratch keeps the first call's contents), and a clear refusal past the
-scratch's capacity."""
+row, the second with fewer rows (the shared scratch keeps the first call's contents), the device's free memory unchanged
+across the call, and a clear refusal past the scratch's capacity."""
 import ctypes as C
 
 import pytest
@@ -36,9 +36,11 @@ def test_forward_static_equals_forward(shape):
         lg = torch.full((rows, A), 3.0, dtype=torch.float32, device=dev)
         v = torch.full((rows,), 3.0, dtype=torch.float32, device=dev)
         torch.cuda.synchronize()
+        free_before = torch.cuda.mem_get_info(dev)[0]
         rc = L.az_net_forward_static(nn._h, C.c_void_p(f.data_ptr()), rows, C.c_void_p(lg.data_ptr()), C.c_void_p(v.data_ptr()), st)
         assert rc == 0, L.az_last_error()
         torch.cuda.synchronize()
+        assert torch.cuda.mem_get_info(dev)[0] == free_before          # the call took no device memory from the driver
         assert torch.equal(lg, want_lg) and torch.equal(v, want_v)
     cap = int(L.az_net_static_max_rows(nn._h))
     assert cap >= 2048
