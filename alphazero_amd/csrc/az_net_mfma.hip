@@ -75,8 +75,18 @@ struct TowerParams {
     int gate_mode, gate_rows;    // with rows_dev: 1 = this launch works only if the count is <= gate_rows, 2 = only if it is above
                                  // (two launches, one per kernel variant; the one the count does not select leaves at once)
     unsigned long long* stamps;  // diagnostic build (-DAZ_STAMP) only: per-workgroup phase cycle sums
+    int lds_bytes;               // diagnostic build (-DAZ_POISON) only: dynamic LDS of the launch, filled with a NaN pattern first
+    int* owner;                  // diagnostic build (-DAZ_POISON) only: [grid + 1] who holds each residual-scratch slot; [grid] counts clashes
 };
 
+#ifdef AZ_POISON
+static int* g_owner_dev = nullptr;   // owner table of the last tower launch (its last word counts slot clashes)
+static int g_owner_grid = 0;
+#endif
+#ifdef AZ_CLOCK
+static unsigned long long* g_clock_dev = nullptr;   // [grid][2] of the last tower launch: shader cycles, 100 MHz ticks per workgroup
+static int g_clock_grid = 0;
+#endif
 #ifdef AZ_STAMP
 #define STAMP(slot)                                                                    \
     do {                                                                               \
@@ -388,10 +398,25 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void k_tower(TowerParams P) {
     (void)taptab;
     const int tid = threadIdx.x;
     uint4* xres_wg = P.xres + (size_t)blockIdx.x * NV * NT;
+#ifdef AZ_POISON
+    // Diagnostic build: whatever a previous workgroup left in this LDS allocation is replaced by NaN bit patterns, and the
+    // workgroup's slot of the residual scratch is claimed, so that (1) outputs that depended on uninitialised LDS or scratch
+    // would change against the regular build (which half of a compute unit's LDS a workgroup gets depends on timing when
+    // two are resident), and (2) two workgroups on one slot would be counted.
+    for (int i = tid; i < P.lds_bytes / 4; i += NT) ((uint32_t*)smem)[i] = 0xFFFFFFFFu;
+    if (tid == 0 && P.owner && atomicExch(&P.owner[blockIdx.x], (int)blockIdx.x + 1) != 0) atomicAdd(&P.owner[gridDim.x], 1);
+    __syncthreads();
+#endif
 #ifdef AZ_STAMP
     unsigned long long stamp_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_last;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last)::"memory");
     stamp_acc[12] = stamp_last;   // absolute start
+#endif
+#ifdef AZ_CLOCK   // diagnostic build: shader cycles and 100 MHz real-time ticks over the workgroup's life -> the in-kernel clock
+    unsigned long long ck_cycles = 0, ck_ticks = 0;
+    if (tid == 0) {
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(ck_cycles), "=s"(ck_ticks)::"memory");
+    }
 #endif
     for (int i = tid; i < ZBYTES / 4; i += NT) ((uint32_t*)zrow)[i] = 0;
     // Two workgroups per compute unit: the issue arbiter prefers the older wave of a SIMD, so in a launch that fills the
@@ -530,6 +555,17 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void k_tower(TowerParams P) {
         }
         STAMP(6);
     }  // item loop
+#ifdef AZ_POISON
+    if (tid == 0 && P.owner && atomicExch(&P.owner[blockIdx.x], 0) != (int)blockIdx.x + 1) atomicAdd(&P.owner[gridDim.x], 1);
+#endif
+#ifdef AZ_CLOCK
+    if (tid == 0 && P.stamps) {
+        unsigned long long c1, r1;
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c1), "=s"(r1)::"memory");
+        P.stamps[(size_t)blockIdx.x * 2] = c1 - ck_cycles;
+        P.stamps[(size_t)blockIdx.x * 2 + 1] = r1 - ck_ticks;
+    }
+#endif
 #ifdef AZ_STAMP
     stamp_acc[13] = stamp_last;   // absolute end
     {
@@ -1309,7 +1345,7 @@ static int fused_forward(MfmaNet* m, const void* feat, int rows, const int* rows
     // works; the other one's workgroups read the count and leave (a few microseconds). Not for bounds so large that
     // few rows are implausible (32 times the limit: inference batches of up to 32 rows per game).
     const bool both = !small && m->device_choice && rows_dev != nullptr && small_rows > 0 && rows <= 32 * (long long)small_rows && !static_scratch_call;
-#ifdef AZ_STAMP
+#if defined(AZ_STAMP) || defined(AZ_CLOCK)
     static unsigned long long* stamp_dev = nullptr;
     static int stamp_grid = 0;
 #endif
@@ -1332,7 +1368,7 @@ static int fused_forward(MfmaNet* m, const void* feat, int rows, const int* rows
         if (both) { P.gate_mode = sm ? 1 : 2; P.gate_rows = small_rows; }
         const bool lean = duo || (sm && lean_small);
         grid = std::min(P.items, lean ? 2 * grid_cap : grid_cap);
-#ifdef AZ_STAMP
+#if defined(AZ_STAMP) || defined(AZ_CLOCK)
         if (grid > stamp_grid) {
             if (stamp_dev) (void)hipFree(stamp_dev);
             (void)hipMalloc((void**)&stamp_dev, (size_t)grid * 8 * 128);
@@ -1340,7 +1376,30 @@ static int fused_forward(MfmaNet* m, const void* feat, int rows, const int* rows
         }
         P.stamps = stamp_dev;
 #endif
+#ifdef AZ_CLOCK
+        g_clock_dev = stamp_dev; g_clock_grid = grid;
+#endif
         const size_t lds = tower_lds_bytes(C, m->NH, TB, c.se_hidden, sm ? 96 : duo ? 176 : m->rows_main, lean);
+#ifdef AZ_POISON
+        {
+            static int* owner_dev = nullptr;
+            static int owner_n = 0;
+            if (grid + 1 > owner_n) {
+                if (owner_dev) (void)hipFree(owner_dev);
+                (void)hipMalloc((void**)&owner_dev, (size_t)(grid + 1) * 4);
+                owner_n = grid + 1;
+                (void)hipMemset(owner_dev, 0, (size_t)owner_n * 4);
+            }
+            (void)hipMemsetAsync(owner_dev, 0, (size_t)(grid + 1) * 4, st);
+            P.owner = owner_dev;
+            P.lds_bytes = (int)lds;
+            g_owner_dev = owner_dev; g_owner_grid = grid;
+            if (!static_scratch_call) {   // residual scratch and head activations start as NaN patterns
+                (void)hipMemsetAsync(xres, 0xFF, xres_bytes(grid_cap, C, m->TB_duo > 0, m->rows_main), st);
+                (void)hipMemsetAsync(hq, 0xFF, (size_t)rows * c.board_size * c.board_size * 2 * m->q * 2, st);
+            }
+        }
+#endif
         switch (C) {
             case 32: hipLaunchKernelGGL((k_tower<32, 8, 1, 32>), dim3(grid), dim3(512), lds, st, P); break;
             case 64:
@@ -1513,3 +1572,31 @@ int mfma_forward_static(MfmaNet* m, const void* feat, int rows, float* logits, f
 }
 
 }  // namespace az
+
+#ifdef AZ_CLOCK
+// Diagnostic build only: per-workgroup in-kernel clock (MHz) of the last tower launch, ascending. Returns the workgroup count.
+extern "C" int az_debug_tower_clock(double* mhz_out, int capacity) {
+    if (!az::g_clock_dev || az::g_clock_grid <= 0) return 0;
+    std::vector<unsigned long long> h((size_t)az::g_clock_grid * 2);
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpy(h.data(), az::g_clock_dev, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    std::vector<double> mhz;
+    for (int g = 0; g < az::g_clock_grid; ++g)
+        if (h[2 * g + 1] > 0) mhz.push_back((double)h[2 * g] / (double)h[2 * g + 1] * 100.0);
+    std::sort(mhz.begin(), mhz.end());
+    const int n = std::min((int)mhz.size(), capacity);
+    for (int i = 0; i < n; ++i) mhz_out[i] = mhz[(size_t)i * mhz.size() / std::max(1, n)];
+    return (int)mhz.size();
+}
+#endif
+
+#ifdef AZ_POISON
+// Diagnostic build only: residual-scratch slots that two workgroups of the last tower launch held at the same time.
+extern "C" int az_debug_slot_clashes(void) {
+    if (!az::g_owner_dev) return -1;
+    int v = -1;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpy(&v, az::g_owner_dev + az::g_owner_grid, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return v;
+}
+#endif

@@ -142,7 +142,9 @@ def cpu_baseline(batch, budget_s=10.0):
                       f"({legs['every_leaf']['moves']} moves, {legs['every_leaf']['nn_rows']} network rows) -> value; leg 2 evaluates a leaf "
                       f"reached by several descents of a batch once, the GPU headline's policy ({legs['dedup']['moves']} moves, "
                       f"{legs['dedup']['nn_rows']} rows) -> value_dedup_policy; cores = min(CPUs this process may use, the box's per-GPU CPU share)",
-            "reference_python_measured_in_build_container": "59.7 sims/s per 1-thread worker (the upstream Python itself, timed where it can be imported; it cannot travel to the GPU box)"}
+            "reference_python_measured_in_build_container": "the upstream Python itself, timed where it can be imported (it cannot travel to the GPU box): "
+                                                            "59.7 sims/s for one 1-thread worker alone; 270 sims/s and 55 games/hour for its own 8-worker "
+                                                            "run_selfplay on 8 cores (8 whole games, 549 moves, 520.6 s; profiles/r03b_upstream_python_8_workers_build_container.json)"}
 
 
 # ------------------------------------------------------------------------------------------------ GPU side legs
