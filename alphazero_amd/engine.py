@@ -14,11 +14,12 @@ import os
 
 from . import _native as N
 
-# AZ_GRAPH_ROUNDS=1: replay a captured HIP graph for the batch rounds of a search where the network allows it, instead of
-# enqueueing the rounds' kernels one by one. Same results; off by default because it measured no faster on any shape (the
-# rounds are a chain of dependent kernels, bound by their execution and not by their launches: 3.4 ms per move for 512
-# games of 64ch x 4 and 15.4 ms for a 40-game 256-simulation search either way).
-GRAPH_ROUNDS = os.environ.get("AZ_GRAPH_ROUNDS", "0") == "1"
+# Replay a captured HIP graph for the batch rounds of a search where the network allows it (launch timing off, scratch
+# reserved) and the stream can be captured (not the legacy default stream), instead of enqueueing the rounds' kernels one by
+# one. Same results. With a move's host half on the device the rounds of a small network are bound by their launches as much
+# as by their execution: 512 games of 64ch x 4 in two lanes 1.96 -> 1.85 ms per move; nothing either way on the 192ch x 12
+# network. AZ_GRAPH_ROUNDS=0 switches it off.
+GRAPH_ROUNDS = os.environ.get("AZ_GRAPH_ROUNDS", "1") != "0"
 
 
 def _ptr(t):
