@@ -1285,7 +1285,7 @@ __global__ __launch_bounds__(64) void k_expand_root(Dev d, const float* logits, 
 
 // Expand the batch's leaves, then revert virtual loss and back up in slot order (mcts.py:203-218). Loads the root's
 // statistics into `rc` and leaves them updated there, not stored.
-template <int PPL>
+template <int PPL, bool STAMPED = false>
 __device__ __forceinline__ void expand_backup_body(const Dev& d, const float* logits, const float* values, int batch_n, double* priors_out,
                                                    RootCache<Apl<PPL>::v>& rc) {
     constexpr int CPL = Apl<PPL>::v;
@@ -1301,7 +1301,7 @@ __device__ __forceinline__ void expand_backup_body(const Dev& d, const float* lo
     }
     const int r0 = d.row_off[g];
     __syncthreads();
-    ESTAMP(1);
+    if (STAMPED) ESTAMP(1);
     const int nu = s_rec[0];
     const int* r_len = s_rec + 4; const int* r_n1 = r_len + B; const int* r_leaf = r_n1 + B; const int* r_uniq = r_leaf + B;
     rc_load<CPL>(d, nb, lane, s_rec[2], s_rec[3], rc);
@@ -1317,7 +1317,7 @@ __device__ __forceinline__ void expand_backup_body(const Dev& d, const float* lo
         }
         s_val[s] = value;
     }
-    ESTAMP(2);
+    if (STAMPED) ESTAMP(2);
     const bool cached = rc.held();
     const int rfirst = rc.rfirst;
     for (int u = 0; u < nu; ++u) {
@@ -1341,7 +1341,7 @@ __device__ __forceinline__ void expand_backup_body(const Dev& d, const float* lo
         }
     }
     __syncthreads();
-    ESTAMP(3);
+    if (STAMPED) ESTAMP(3);
     double* vsum = d.vsum + nb;
     int* visits = d.visits + nb;
     // Deeper nodes than the root's children are updated in memory.
@@ -1408,7 +1408,7 @@ __global__ __launch_bounds__(64) void k_expand_select(Dev d, const float* logits
     const int passes = d.sc[sc_idx(g, SC_PASSES)], moves = d.sc[sc_idx(g, SC_MOVES)];
     RootCache<Apl<PPL>::v> rc;
     ESTAMP(0);
-    expand_backup_body<PPL>(d, logits, values, batch_prev, priors_out, rc);
+    expand_backup_body<PPL, true>(d, logits, values, batch_prev, priors_out, rc);
     __threadfence_block();
     __syncthreads();   // deeper statistics written by the backup are read by the descents; the two phases share the LDS
     ESTAMP(4);

@@ -34,8 +34,6 @@ for move in (1, 40, 80, 110):
     ok = t[:, 7] > 0
     print(f"   waves above 1.5x the median total: {int((tot[ok] > 1.5 * np.median(tot[ok])).sum())} of {int(ok.sum())}; p50 {np.median(tot[ok]):.1f} p90 {np.percentile(tot[ok], 90):.1f} p99 {np.percentile(tot[ok], 99):.1f}")
     for i, nm in enumerate(names[:7]):
-        if i in (0, 3):
-            continue      # stamps 1-3 come from the final k_expand_backup launch: the differences across them mean nothing
         print(f"   {nm:22s} mean {dt[ok, i].mean():6.2f}  p90 {np.percentile(dt[ok, i], 90):6.2f}  max {dt[ok, i].max():6.2f}")
     f = buf.reshape(n, 16)[:, 8:16].astype(np.int64)
     okf = (f > 0).all(axis=1)
