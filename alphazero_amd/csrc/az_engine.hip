@@ -582,9 +582,6 @@ struct RootCache {
     int vis[CPL], nch[CPL], act[CPL];
     int cf[CPL];   // child_off of the child: index of its first child, or the outcome code of a terminal one (term_code)
     __device__ bool held() const { return rnc > 0 && rnc <= 64 * CPL; }
-    // what a short descent needs to know about child k in one word: children (10 bits), action (10 bits), outcome code + 1
-    // of a terminal child whose outcome is known (0: not known; 2 bits)
-    __device__ int packed(int k) const { return nch[k] | (act[k] << 10) | ((cf[k] <= -2 ? -cf[k] - 1 : 0) << 20); }
 };
 
 template <int CPL>
@@ -637,20 +634,170 @@ __device__ inline int rc_read(const int (&arr)[CPL], int idx) {
 // the path ends at the root), the leaf node; then the slots of the distinct leaves in row order.
 __device__ inline int brec_words(const Dev& d) { return 4 + 4 * d.B; }
 
+// A child's number of children (10 bits) and action (10 bits) in one word.
+__device__ inline int pack_child(int nch, int act) { return nch | (act << 10); }
+
+// The children of one tree node in the wave's registers for the descents of a batch (child i: lane i & 63, slot i >> 6).
+// With virtual loss the descents of a batch mostly walk the same path, so a level loaded by one descent serves the next
+// ones: they pick among its children, and apply their virtual loss to the pick, without a memory access. The node's own
+// statistics are an entry of the level above.
+template <int CPL>
+struct Level {
+    int node, n, first;       // whose children (-1: none), how many, index of the first
+    int pv0;                  // visit count of the node that lane 0's exploration-table entries belong to
+    int guess;                // the child picked last (with virtual loss, usually picked again)
+    bool dirty;               // vis / vsum differ from memory
+    double t_pbc, t_sqn;      // lane i: exploration-table entries for pv0 + i visits of the node (pv0 without virtual loss)
+    float t_pbc32, t_sqn32;
+    double prior[CPL], vsum[CPL];
+    float pr32[CPL], vs32[CPL];
+    int vis[CPL], pk[CPL], cf[CPL];   // cf: child_off of the child (first grandchild, or the outcome code of a terminal child)
+};
+
+template <int CPL>
+__device__ __forceinline__ void level_table(const Dev& d, int lane, Level<CPL>& lv, int pv) {
+    const int t_idx = min(pv + (d.vl > 0.0 ? lane : 0), d.tab_len - 1);
+    lv.pv0 = pv;
+    lv.t_pbc = d.pbc[t_idx]; lv.t_sqn = d.sqn[t_idx];
+    lv.t_pbc32 = (float)lv.t_pbc; lv.t_sqn32 = (float)lv.t_sqn;
+}
+
+template <int CPL>
+__device__ __forceinline__ void level_flush(const Dev& d, size_t nb, int lane, Level<CPL>& lv) {
+    if (lv.node >= 0 && lv.dirty) {
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) {
+            const int i = lane + 64 * k;
+            if (i < lv.n) { d.visits[nb + lv.first + i] = lv.vis[k]; d.vsum[nb + lv.first + i] = lv.vsum[k]; }
+        }
+    }
+    lv.dirty = false;
+}
+
+// pv: the node's visit count now.
+template <int CPL>
+__device__ __forceinline__ void level_load(const Dev& d, size_t nb, int lane, int node, int first, int n, int pv, Level<CPL>& lv) {
+    lv.node = node; lv.first = first; lv.n = n; lv.guess = -1; lv.dirty = false;
+    level_table<CPL>(d, lane, lv, pv);
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+        const int i = lane + 64 * k;
+        lv.prior[k] = 0.0; lv.vsum[k] = 0.0; lv.vis[k] = 0; lv.pk[k] = 0; lv.cf[k] = 0;
+        if (i < n) {
+            const size_t x = nb + first + i;
+            lv.prior[k] = d.prior[x]; lv.vsum[k] = d.vsum[x]; lv.vis[k] = d.visits[x]; lv.cf[k] = d.child_off[x];
+            lv.pk[k] = pack_child(d.n_child[x], d.action[x]);
+        }
+        lv.pr32[k] = (float)lv.prior[k]; lv.vs32[k] = (float)lv.vsum[k];
+    }
+}
+
+// arr[idx >> 6] of lane idx & 63; idx must be wave-uniform
+template <int CPL>
+__device__ __forceinline__ int lane_pick(const int (&arr)[CPL], int lane, int idx) {
+    int v = 0;
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) v = lane + 64 * k == idx ? arr[k] : v;
+    return __builtin_amdgcn_readlane(v, idx & 63);
+}
+
+// mcts.py:97-116 over the children held in `lv`; pv: the node's visit count now. Returns the child (wave-uniform) or -1.
+// Pre-selection in float with error intervals: a child's float score sc and a bound e on its distance from the float64
+// score of mcts.py:104-108 (at most eleven roundings of 2^-23 relative each on the exploration and the value term: below
+// 1.4e-6 (|u| + |q|); e takes 4e-6). Only children with sc + e >= max(sc - e) can hold the float64 maximum; when exactly one
+// does, it is the child the float64 arg-max returns, and the float64 scores are not needed. Before the wave-wide maximum
+// the child picked last is tried alone against the others' upper bounds. Ties and near-ties take the float64 arg-max.
+template <int CPL>
+__device__ __forceinline__ int level_pick(const Dev& d, int lane, Level<CPL>& lv, int pv) {
+    int tslot = pv - lv.pv0;
+    if (d.vl > 0.0 ? (tslot < 0 || tslot >= 64) : tslot != 0) { level_table<CPL>(d, lane, lv, pv); tslot = 0; }
+    {
+        const float pbc32 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lv.t_pbc32), tslot));
+        const float sq32 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lv.t_sqn32), tslot));
+        float hi[CPL], lo_k[CPL], lo = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) {
+            const bool valid = lane + 64 * k < lv.n;
+            const int vc = lv.vis[k];
+            const float fvc = (float)vc;
+            const float u = pbc32 * (sq32 * __builtin_amdgcn_rcpf(fvc + 1.0f)) * lv.pr32[k];
+            const float q = vc == 0 ? 0.0f : lv.vs32[k] * __builtin_amdgcn_rcpf(fvc);
+            const float sc = u - q, e = 4e-6f * (fabsf(u) + fabsf(q)) + 1e-30f;
+            hi[k] = valid ? sc + e : -INFINITY;
+            lo_k[k] = valid ? sc - e : -INFINITY;
+            lo = fmaxf(lo, lo_k[k]);
+        }
+        float m_lo = -INFINITY;
+        int total = 0, ci = 0;
+        if (lv.guess >= 0) {
+            float lo_g = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < CPL; ++k) lo_g = lane + 64 * k == lv.guess ? lo_k[k] : lo_g;
+            m_lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lo_g), lv.guess & 63));
+#pragma unroll
+            for (int k = 0; k < CPL; ++k) total += __popcll(__ballot(hi[k] >= m_lo));
+            ci = lv.guess;
+        }
+        if (total != 1) {
+            m_lo = wave_max_f32(lo);
+            total = 0;
+#pragma unroll
+            for (int k = 0; k < CPL; ++k) {
+                const unsigned long long bal = __ballot(hi[k] >= m_lo);
+                total += __popcll(bal);
+                if (bal) ci = 64 * k + __ffsll((long long)bal) - 1;
+            }
+        }
+        if (total == 1 && m_lo > -1e17f) {   // (scores at or below -1e18 never win: mcts.py:100, :109)
+            lv.guess = ci;
+            return ci;
+        }
+    }
+    const double pbc = readlane_f64(lv.t_pbc, tslot), sq = readlane_f64(lv.t_sqn, tslot);
+    double best = -INFINITY;
+    int best_i = 0x7fffffff;
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+        const int i = lane + 64 * k;
+        if (i < lv.n) {
+            int vc = lv.vis[k];
+            asm volatile("" : "+v"(vc));   // keeps these divisions here: hoisted, they would run in front of every pick
+            const double pb = pbc * (sq / ((double)vc + 1.0));
+            const double prior_score = pb * lv.prior[k];
+            const double value_score = -(vc == 0 ? 0.0 : lv.vsum[k] / (double)vc);
+            const double score = prior_score + value_score;
+            if (score > -1e18 && (score > best)) { best = score; best_i = i; }
+        }
+    }
+    wave_argmax(best, best_i);
+    if (best_i == 0x7fffffff) return -1;   // mcts.py:114-115
+    lv.guess = best_i;
+    return best_i;
+}
+
+// Levels below the root that a wave keeps in registers (the root's children always are): leaves down to depth
+// kDeepLevels + 1 are reached without memory accesses once their path has been walked in the batch.
+#ifdef AZ_DEEP_LEVELS   // diagnostic builds
+template <int CPL> struct DeepLevels { static constexpr int v = AZ_DEEP_LEVELS; };
+#else
+template <int CPL> struct DeepLevels { static constexpr int v = CPL <= 2 ? 3 : (CPL == 3 ? 2 : 1); };
+#endif
+
 // mcts.py:181-199: batch_n descents for game blockIdx.x. `rc` holds the root's statistics (rc_load) and is left updated,
 // not stored. rows_ctr: null (the row scan kernel assigns the rows), or the counter this batch's rows are allotted from.
 template <int PPL>
 __device__ __forceinline__ void select_body(const Dev& d, int batch_n, RootCache<Apl<PPL>::v>& rc, int root_passes, int root_moves,
                                             double t_pbc, double t_sqn, int t_base, int* rows_ctr) {
     constexpr int CPL = Apl<PPL>::v;
+    constexpr int DC = DeepLevels<CPL>::v;
     __shared__ BoardLds<PPL> b;
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
     uint64_t* seen_lds = (uint64_t*)dyn;
     double* tc_val = (double*)(seen_lds + d.seen_cap);   // outcomes of the terminal leaves met in this batch ...
     int* path_lds = (int*)(tc_val + d.B);            // the current descent's nodes
     int* uniq_lds = path_lds + d.max_depth;          // (slot, leaf node) of the batch's distinct leaves so far
-    // Per-descent results wait in LDS and go to global memory after the last descent: stores and loads share one
-    // counter, so a store in flight would stall the next descent at its first wait for a load (about 2 us each).
+    // Per-descent results wait in registers / LDS and go to global memory after the last descent: stores and loads share
+    // one counter, so a store in flight would stall the next descent at its first wait for a load (about 2 us each).
     constexpr int PSTAGE = 8;                        // path nodes staged per descent; a longer path is written at once
     int* st_len = uniq_lds + 2 * d.B;                // [B]
     int* st_ref = st_len + d.B;                      // [B]
@@ -668,25 +815,27 @@ __device__ __forceinline__ void select_body(const Dev& d, int batch_n, RootCache
 
     // The descent itself needs no board: children only exist for legal moves, and whether a node is terminal
     // follows from the pass count and the move count (go.py:205-206). The moves are replayed on an LDS board
-    // only for a terminal leaf, whose outcome needs the final position (the leaf gather replays the others).
+    // only for a terminal leaf whose outcome is not known yet (the leaf gather replays the others).
     const int rnc = rc.rnc, rfirst = rc.rfirst;
     const bool cached = rc.held();
-    // the root's visit count during descent `slot` is r_vis + slot with virtual loss (else r_vis): lane i holds the
-    // exploration-table entries of t_base + i, fetched before the root's statistics were known; t_base is the visit count
-    // the caller expects (the simulations finished so far)
-    if (rc.r_vis != t_base) {
-        const int t_idx = min(rc.r_vis + (d.vl > 0.0 ? lane : 0), d.tab_len - 1);
-        t_pbc = d.pbc[t_idx]; t_sqn = d.sqn[t_idx];
-    }
-    const int r_vis0 = rc.r_vis;
-    // float copies of the root children's priors and value sums and of the exploration-table entries for the interval
-    // pre-selection below
-    const float t_pbc32 = (float)t_pbc, t_sqn32 = (float)t_sqn;
-    float pr32[CPL], vs32[CPL];
+    // The root's children as level 0. Lane i holds the exploration-table entries of t_base + i visits, fetched before the
+    // root's statistics were known; t_base is the visit count the caller expects (the simulations finished so far).
+    Level<CPL> lv[DC + 1];
+    {
+        Level<CPL>& L0 = lv[0];
+        L0.node = 0; L0.n = cached ? rnc : 0; L0.first = rfirst; L0.pv0 = t_base; L0.guess = -1; L0.dirty = false;
+        L0.t_pbc = t_pbc; L0.t_sqn = t_sqn; L0.t_pbc32 = (float)t_pbc; L0.t_sqn32 = (float)t_sqn;
 #pragma unroll
-    for (int k = 0; k < CPL; ++k) { pr32[k] = (float)rc.prior[k]; vs32[k] = (float)rc.vsum[k]; }
+        for (int k = 0; k < CPL; ++k) {
+            L0.prior[k] = rc.prior[k]; L0.vsum[k] = rc.vsum[k]; L0.vis[k] = rc.vis[k]; L0.cf[k] = rc.cf[k];
+            L0.pk[k] = pack_child(rc.nch[k], rc.act[k]);
+            L0.pr32[k] = (float)rc.prior[k]; L0.vs32[k] = (float)rc.vsum[k];
+        }
+    }
+#pragma unroll
+    for (int L = 1; L <= DC; ++L) { lv[L].node = -1; lv[L].n = 0; lv[L].dirty = false; lv[L].guess = -1; }
+
     int last_node = -1, last_ref = -1;   // the distinct leaf found last (most descents of a batch end in it again)
-    int guess = -1;                      // the root child chosen last (with virtual loss, usually chosen again)
     // Per-descent results: lane s keeps those of slot s in registers (slots from 64 on: LDS) until they are written out
     int my_len = 0, my_ref = 0, my_n1 = 0, my_leaf = 0;
     auto put_record = [&](int slot, int len, int ref, int n1, int leaf) {   // slot is wave-uniform
@@ -697,140 +846,51 @@ __device__ __forceinline__ void select_body(const Dev& d, int batch_n, RootCache
             st_len[slot] = len; st_ref[slot] = ref; st_n1[slot] = n1; st_leaf[slot] = leaf;
         }
     };
-    int pk[CPL];   // rc.packed(k), kept up to date where a child's fields change
-#pragma unroll
-    for (int k = 0; k < CPL; ++k) pk[k] = rc.packed(k);
     for (int slot = 0; slot < batch_n; ++slot) {
         if (slot < 8) ESTAMP_CYCLES(8 + slot);
-        // The usual descent ends in a child of the root that has no children yet: handled here without the general loop.
-        // Pre-selection in float with error intervals: a child's float score sc and a bound e on its distance from the
-        // float64 score of mcts.py:104-108 (at most eleven roundings of 2^-23 relative each on the exploration and the value
-        // term: below 1.4e-6 (|u| + |q|); e takes 4e-6). Only children with sc + e >= max(sc - e) can hold the float64
-        // maximum; when exactly one does, it is the child the float64 arg-max returns, and the float64 scores are not
-        // needed. Ties, near-ties and every other kind of descent take the general loop below.
-        {
-            const int tslot = d.vl > 0.0 ? rc.r_vis - r_vis0 : 0;
-            if (cached && tslot < 64 && root_passes < 2 && root_moves < 2 * d.np && d.max_depth > 2) {
-                const float pbc32 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t_pbc32), tslot));
-                const float sq32 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t_sqn32), tslot));
-                float hi[CPL], lo_k[CPL], lo = -INFINITY;
-#pragma unroll
-                for (int k = 0; k < CPL; ++k) {
-                    const bool valid = lane + 64 * k < rnc;
-                    const int vc = rc.vis[k];
-                    const float fvc = (float)vc;
-                    const float u = pbc32 * (sq32 * __builtin_amdgcn_rcpf(fvc + 1.0f)) * pr32[k];
-                    const float q = vc == 0 ? 0.0f : vs32[k] * __builtin_amdgcn_rcpf(fvc);
-                    const float sc = u - q, e = 4e-6f * (fabsf(u) + fabsf(q)) + 1e-30f;
-                    hi[k] = valid ? sc + e : -INFINITY;
-                    lo_k[k] = valid ? sc - e : -INFINITY;
-                    lo = fmaxf(lo, lo_k[k]);
-                }
-                // first against the lower bound of the child chosen last: if no other child's upper bound reaches it, that
-                // child holds the maximum again and the wave-wide maximum is not needed
-                float m_lo = -INFINITY;
-                int total = 0, ci = 0;
-                if (guess >= 0) {
-                    float lo_g = -INFINITY;
-#pragma unroll
-                    for (int k = 0; k < CPL; ++k) lo_g = lane + 64 * k == guess ? lo_k[k] : lo_g;
-                    m_lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lo_g), guess & 63));
-#pragma unroll
-                    for (int k = 0; k < CPL; ++k) total += __popcll(__ballot(hi[k] >= m_lo));
-                    ci = guess;
-                }
-                if (total != 1) {
-                    m_lo = wave_max_f32(lo);
-                    total = 0;
-#pragma unroll
-                    for (int k = 0; k < CPL; ++k) {
-                        const unsigned long long bal = __ballot(hi[k] >= m_lo);
-                        total += __popcll(bal);
-                        if (bal) ci = 64 * k + __ffsll((long long)bal) - 1;
-                    }
-                }
-                if (total == 1 && m_lo > -1e17f) {   // (scores at or below -1e18 never win: mcts.py:100, :109)
-                        int word = 0;
-#pragma unroll
-                    for (int k = 0; k < CPL; ++k) word = lane + 64 * k == ci ? pk[k] : word;
-                    word = __builtin_amdgcn_readlane(word, ci & 63);
-                    const int nchc = word & 1023, actc = (word >> 10) & 1023;
-                    const int passes1 = actc == d.np ? root_passes + 1 : 0;
-                    const bool terminal1 = passes1 >= 2 || root_moves + 1 >= 2 * d.np;
-                    const int cfc = (word >> 20) ? -(word >> 20) - 1 : 0;
-                    if (nchc == 0 && (!terminal1 || is_term_code(cfc))) {
-                        const int node = rfirst + ci;
-                                guess = ci;
-                        int ref = slot;
-                        if (terminal1) {   // mcts.py:191-192, outcome known from an earlier descent
-                            ref = -1;
-                            n_term += 1;
-                            if (lane == 0) d.term_value[g * d.B + slot] = term_outcome(cfc);
-                        } else if (d.dedup) {
-                            if (node == last_node) ref = last_ref;
-                            else
-                                for (int u = 0; u < n_unique; ++u)
-                                    if (uniq_lds[2 * u + 1] == node) { ref = uniq_lds[2 * u]; break; }
-                        }
-                        if (ref == slot) {
-                            if (lane == 0) { uniq_lds[2 * n_unique] = slot; uniq_lds[2 * n_unique + 1] = node; }
-                            n_unique += 1;
-                        }
-                        put_record(slot, 2, ref, node, node);
-                        if (!terminal1) { last_node = node; last_ref = ref; }
-                        depth_sum += 1;
-                        max_depth = max(max_depth, 1);
-                                if (d.vl > 0.0) {  // mcts.py:196-199
-                            rc.r_vis += 1;
-                            rc.r_vsum -= d.vl;
-#pragma unroll
-                            for (int k = 0; k < CPL; ++k)
-                                if (lane + 64 * k == ci) { rc.vis[k] += 1; rc.vsum[k] -= d.vl; vs32[k] = (float)rc.vsum[k]; }
-                        }
-                                wave_sync();
-                                continue;
-                    }
-                }
-            }
-        }
         int* path = d.path + ((size_t)g * d.B + slot) * d.max_depth;
-        int node = 0, len = 1, nc = rnc;
-        int child_vis = -1;   // visit count of the current node when it is a root child held in registers
-        int root_child = -1;  // index of the root child the descent went through
+        int node = 0, len = 1, nc = rnc, first = rfirst;
+        int pv = cached ? rc.r_vis : -1;     // the current node's visit count (-1: in memory)
+        int node_cf = 0;                     // child_off of the current node when it was picked from a register level
         int passes = root_passes, moves = root_moves;
+        int pick[DC + 1];                    // the child picked at each register level (-1: level not reached)
+        bool failed = false, walking = cached;
         if (lane == 0) path_lds[0] = 0;
-        bool failed = false;
-        while (true) {
-            if (nc == 0 || passes >= 2 || moves >= 2 * d.np || len >= d.max_depth) break;
-            // mcts.py:97-116
-            const bool at_root = cached && node == 0;
-            const int first = at_root ? rfirst : ((len == 2 && root_child >= 0) ? rc_read<CPL>(rc.cf, root_child) : child_off[node]);
-            double pbc, sq;
-            const int tslot = d.vl > 0.0 ? rc.r_vis - r_vis0 : 0;   // = slot with virtual loss
-            if (at_root && tslot < 64) {   // wave-uniform: register reads, no lane shuffle
-                pbc = readlane_f64(t_pbc, tslot); sq = readlane_f64(t_sqn, tslot);
-            } else {
-                int pv = at_root ? rc.r_vis : (child_vis >= 0 ? child_vis : visits[node]);
-                pv = pv < d.tab_len ? pv : d.tab_len - 1;
-                pbc = d.pbc[pv]; sq = d.sqn[pv];
-            }
-            double best = -INFINITY;
-            int best_i = 0x7fffffff;
-            if (at_root) {
 #pragma unroll
-                for (int k = 0; k < CPL; ++k) {
-                    const int i = lane + 64 * k;
-                    if (i < nc) {
-                        int vc = rc.vis[k];
-                        asm volatile("" : "+v"(vc));   // keeps these divisions here: hoisted, they would run in front of every short descent
-                        double pb = pbc * (sq / ((double)vc + 1.0));
-                        const double prior_score = pb * rc.prior[k];
-                        const double value_score = -(vc == 0 ? 0.0 : rc.vsum[k] / (double)vc);
-                        const double score = prior_score + value_score;
-                        if (score > -1e18 && (score > best)) { best = score; best_i = i; }
-                    }
-                }
-            } else {
+        for (int L = 0; L <= DC; ++L) {
+            pick[L] = -1;
+            if (!walking) continue;
+            if (nc == 0 || passes >= 2 || moves >= 2 * d.np || len >= d.max_depth) { walking = false; continue; }
+            Level<CPL>& lvl = lv[L];
+            if (L > 0 && lvl.node != node) {
+                level_flush<CPL>(d, nb, lane, lvl);
+                level_load<CPL>(d, nb, lane, node, first, nc, pv, lvl);
+            }
+            const int ci = level_pick<CPL>(d, lane, lvl, pv);
+            if (ci < 0) { failed = true; walking = false; continue; }
+            pick[L] = ci;
+            const int word = lane_pick<CPL>(lvl.pk, lane, ci);
+            node_cf = lane_pick<CPL>(lvl.cf, lane, ci);
+            pv = lane_pick<CPL>(lvl.vis, lane, ci);
+            node = lvl.first + ci;
+            nc = word & 1023;
+            first = node_cf;
+            const int act = (word >> 10) & 1023;
+            passes = act == d.np ? passes + 1 : 0;
+            moves += 1;
+            if (lane == 0) path_lds[len] = node;
+            len += 1;
+        }
+        const int reg_len = len;             // path nodes whose statistics are in registers
+        if (!failed && (walking || !cached)) {
+            // below the register levels (or a root whose children they cannot hold): children read from memory
+            while (true) {
+                if (nc == 0 || passes >= 2 || moves >= 2 * d.np || len >= d.max_depth) break;
+                int pvv = pv >= 0 ? pv : visits[node];
+                pvv = pvv < d.tab_len ? pvv : d.tab_len - 1;
+                const double pbc = d.pbc[pvv], sq = d.sqn[pvv];
+                double best = -INFINITY;
+                int best_i = 0x7fffffff;
                 for (int i0 = 0; i0 < nc; i0 += 64) {
                     const int i = i0 + lane;
                     if (i < nc) {
@@ -842,19 +902,19 @@ __device__ __forceinline__ void select_body(const Dev& d, int batch_n, RootCache
                         if (score > -1e18 && (score > best)) { best = score; best_i = i; }
                     }
                 }
+                wave_argmax(best, best_i);
+                if (best_i == 0x7fffffff) { failed = true; break; }  // mcts.py:114-115
+                node = first + best_i;   // best_i is wave-uniform (wave_argmax returns it from one lane)
+                const int act = (int)action[node];
+                nc = (int)n_child[node];
+                node_cf = child_off[node];
+                first = node_cf;
+                pv = -1;
+                passes = act == d.np ? passes + 1 : 0;
+                moves += 1;
+                if (lane == 0) path_lds[len] = node;
+                len += 1;
             }
-            wave_argmax(best, best_i);
-            if (best_i == 0x7fffffff) { failed = true; break; }  // mcts.py:114-115
-            node = first + best_i;
-            if (at_root) root_child = best_i;
-            // best_i is wave-uniform (wave_argmax returns it from one lane)
-            const int act = at_root ? rc_read<CPL>(rc.act, best_i) : (int)action[node];
-            nc = at_root ? rc_read<CPL>(rc.nch, best_i) : (int)n_child[node];
-            child_vis = at_root ? rc_read<CPL>(rc.vis, best_i) : -1;
-            passes = act == d.np ? passes + 1 : 0;
-            moves += 1;
-            if (lane == 0) path_lds[len] = node;
-            len += 1;
         }
         if (failed) { if (lane == 0) atomicMin(&d.ctl[1], (int)AZ_ERR_NOCHILD); }
         wave_sync();
@@ -865,30 +925,34 @@ __device__ __forceinline__ void select_body(const Dev& d, int batch_n, RootCache
         const int gs = g * d.B + slot;
         int ref;
         if (terminal) {  // mcts.py:191-192
-            int hit = -1;
-            for (int u = 0; u < n_tc; ++u)
-                if (tc_node[u] == node) { hit = u; break; }
             double v;
-            int known = 0;
-            if (hit < 0) known = (len == 2 && root_child >= 0) ? rc_read<CPL>(rc.cf, root_child) : child_off[node];
-            if (hit >= 0) {
-                v = tc_val[hit];
-            } else if (is_term_code(known)) {
-                v = term_outcome(known);
+            if (len > 1 && is_term_code(node_cf)) {   // scored by an earlier descent (of this batch or another)
+                v = term_outcome(node_cf);
             } else {
-                Geo<PPL> geo;
-                geo_init<PPL>(geo, d.n, lane);
-                Sim<PPL> s;
-                __syncthreads();
-                sim_load_root<PPL>(d, g, lane, geo, b, seen_lds, s);
-                for (int i = 1; i < len; ++i) sim_play<PPL>(d, lane, geo, b, seen_lds, nullptr, s, (int)action[path_lds[i]]);
-                v = sim_outcome<PPL>(d, geo, b, s);
-                if (lane == 0) { tc_node[n_tc] = node; tc_val[n_tc] = v; d.child_off[nb + node] = term_code(v); }
-                n_tc += 1;
-                if (len == 2 && root_child >= 0) {
+                int hit = -1;
+                for (int u = 0; u < n_tc; ++u)
+                    if (tc_node[u] == node) { hit = u; break; }
+                if (hit >= 0) {
+                    v = tc_val[hit];
+                } else {
+                    Geo<PPL> geo;
+                    geo_init<PPL>(geo, d.n, lane);
+                    Sim<PPL> s;
+                    __syncthreads();
+                    sim_load_root<PPL>(d, g, lane, geo, b, seen_lds, s);
+                    for (int i = 1; i < len; ++i) sim_play<PPL>(d, lane, geo, b, seen_lds, nullptr, s, (int)action[path_lds[i]]);
+                    v = sim_outcome<PPL>(d, geo, b, s);
+                    if (lane == 0) { tc_node[n_tc] = node; tc_val[n_tc] = v; if (len > 1) d.child_off[nb + node] = term_code(v); }
+                    n_tc += 1;
+                    // the level that holds the node learns the outcome too
 #pragma unroll
-                    for (int k = 0; k < CPL; ++k)
-                        if (lane + 64 * k == root_child) { rc.cf[k] = term_code(v); pk[k] = rc.packed(k); }
+                    for (int L = 0; L <= DC; ++L) {
+                        if (L + 2 == len && pick[L] >= 0) {
+#pragma unroll
+                            for (int k = 0; k < CPL; ++k)
+                                if (lane + 64 * k == pick[L]) lv[L].cf[k] = term_code(v);
+                        }
+                    }
                 }
             }
             if (lane == 0) d.term_value[gs] = v;
@@ -911,9 +975,8 @@ __device__ __forceinline__ void select_body(const Dev& d, int batch_n, RootCache
             }
             last_node = node; last_ref = ref;
         }
-        const int n1 = len > 1 ? (root_child >= 0 ? rfirst + root_child : path_lds[1]) : -1;   // the root child on the path
+        const int n1 = len > 1 ? (pick[0] >= 0 ? rfirst + pick[0] : path_lds[1]) : -1;   // the root child on the path
         put_record(slot, len, ref, n1, node);
-        if (root_child >= 0) guess = root_child;
         depth_sum += len - 1;
         max_depth = max(max_depth, len - 1);
         wave_sync();
@@ -921,14 +984,18 @@ __device__ __forceinline__ void select_body(const Dev& d, int batch_n, RootCache
             if (cached) {
                 rc.r_vis += 1;
                 rc.r_vsum -= d.vl;
-                if (len > 1) {
-                    const int ci = n1 - rfirst;
 #pragma unroll
-                    for (int k = 0; k < CPL; ++k)
-                        if (lane + 64 * k == ci) { rc.vis[k] += 1; rc.vsum[k] -= d.vl; vs32[k] = (float)rc.vsum[k]; }
+                for (int L = 0; L <= DC; ++L) {
+                    if (pick[L] >= 0) {
+                        Level<CPL>& lvl = lv[L];
+#pragma unroll
+                        for (int k = 0; k < CPL; ++k)
+                            if (lane + 64 * k == pick[L]) { lvl.vis[k] += 1; lvl.vsum[k] -= d.vl; lvl.vs32[k] = (float)lvl.vsum[k]; }
+                        lvl.dirty = true;
+                    }
                 }
             }
-            for (int i = (cached ? 2 : 0) + lane; i < len; i += 64) {
+            for (int i = (cached ? reg_len : 0) + lane; i < len; i += 64) {
                 const int pn = path_lds[i];
                 visits[pn] += 1;
                 vsum[pn] -= d.vl;
@@ -937,6 +1004,15 @@ __device__ __forceinline__ void select_body(const Dev& d, int batch_n, RootCache
         wave_sync();
     }
     ESTAMP(5);
+    // the levels go back to memory (the backup that follows the network updates deeper nodes there), the root's to `rc`
+#pragma unroll
+    for (int L = 1; L <= DC; ++L) level_flush<CPL>(d, nb, lane, lv[L]);
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) { rc.vis[k] = lv[0].vis[k]; rc.vsum[k] = lv[0].vsum[k]; rc.cf[k] = lv[0].cf[k]; }
+    // this game's rows: allotted from the batch's counter (their order among the games does not matter); asked for first,
+    // so that the answer travels while the record is written
+    int row0 = 0;
+    if (rows_ctr && lane == 0 && n_unique > 0) row0 = atomicAdd(rows_ctr, n_unique);
     // the batch's results: the record for the expansion, the path lengths and slot tables the leaf gather reads
     int* brec = d.brec + (size_t)g * brec_words(d);
     for (int sl = lane; sl < batch_n; sl += 64) {
@@ -953,24 +1029,23 @@ __device__ __forceinline__ void select_body(const Dev& d, int batch_n, RootCache
             for (int i = 0; i < len; ++i) path[i] = st_path[sl * PSTAGE + i];
     }
     for (int u = lane; u < n_unique; u += 64) { d.uniq_slot[g * d.B + u] = uniq_lds[2 * u]; brec[4 + 3 * d.B + u] = uniq_lds[2 * u]; }
-    int row0 = 0;
-    if (rows_ctr) {   // this game's rows: allotted from the batch's counter (their order among the games does not matter)
-        if (lane == 0 && n_unique > 0) row0 = atomicAdd(rows_ctr, n_unique);
-        row0 = __builtin_amdgcn_readfirstlane(row0);
-        for (int u = lane; u < n_unique; u += 64) { d.row_game[row0 + u] = g; d.row_slot[row0 + u] = uniq_lds[2 * u]; }
-    }
-    ESTAMP(6);
     if (lane == 0) {
         brec[0] = n_unique; brec[1] = 0; brec[2] = rnc; brec[3] = rfirst;
-        if (rows_ctr) d.row_off[g] = row0;
         d.n_unique[g] = n_unique;
-        long long* gs = d.gstats + (size_t)g * 8;
-        gs[ST_DEPTH_SUM] += depth_sum;
-        gs[ST_MAX_DEPTH] = max(gs[ST_MAX_DEPTH], (long long)max_depth);
-        gs[ST_TERMINAL] += n_term;
-        gs[ST_SIMS] += batch_n;
-        gs[ST_ROWS_RAW] += batch_n - n_term;
-        gs[ST_ROWS] += n_unique;
+        // per-game counters, nobody else's: atomics without a result, so that the wave does not wait for a read-modify-write
+        unsigned long long* gs = (unsigned long long*)(d.gstats + (size_t)g * 8);
+        atomicAdd(&gs[ST_DEPTH_SUM], (unsigned long long)depth_sum);
+        atomicMax((long long*)&gs[ST_MAX_DEPTH], (long long)max_depth);
+        atomicAdd(&gs[ST_TERMINAL], (unsigned long long)n_term);
+        atomicAdd(&gs[ST_SIMS], (unsigned long long)batch_n);
+        atomicAdd(&gs[ST_ROWS_RAW], (unsigned long long)(batch_n - n_term));
+        atomicAdd(&gs[ST_ROWS], (unsigned long long)n_unique);
+    }
+    ESTAMP(6);
+    if (rows_ctr) {
+        row0 = __builtin_amdgcn_readfirstlane(row0);
+        for (int u = lane; u < n_unique; u += 64) { d.row_game[row0 + u] = g; d.row_slot[row0 + u] = uniq_lds[2 * u]; }
+        if (lane == 0) d.row_off[g] = row0;
     }
 }
 

@@ -25,7 +25,6 @@ NATIVE_ROUNDS = os.environ.get("AZ_NATIVE_ROUNDS", "1") != "0"   # 0: one call p
 # 0: the per-move host half (policy targets, move sampling, resignation, play, status) in NumPy with a device round trip per
 # piece, as before the native lane (az_lane_*) existed; same games either way (A/B timing and cross-check)
 NATIVE_LANE = os.environ.get("AZ_NATIVE_LANE", "1") != "0"
-_LANE_DELAY = float(os.environ.get("AZ_LANE_DELAY_MS", "0")) * 1e-3     # experiment: host pause between a lane's moves
 
 
 @dataclass
@@ -413,8 +412,6 @@ class _Lane:
                     N.check(N.lib().az_lane_prepare(self.nl, self._stream_ptr()), "az_lane_prepare")
         c["t_host_policy"] += time.perf_counter() - t0
         self.step_no += 1
-        if _LANE_DELAY > 0:
-            time.sleep(_LANE_DELAY)
 
     def finish(self):
         if self.inflight is None:
@@ -529,7 +526,7 @@ class BatchedSelfPlay:
         self.counters = dict(moves=0, sims=0, nn_rows=0, nn_rows_nodedup=0, games=0, steps=0, depth_sum=0, graph_replays=0,
                              t_host_rng=0.0, t_host_policy=0.0, t_samples=0.0)
         share = [self.G // lanes + (1 if i < self.G % lanes else 0) for i in range(lanes)]
-        self.lanes = [_Lane(self, i, g, model, precision, dedup_leaves, rng_threads, own_stream=lanes > 1)
+        self.lanes = [_Lane(self, i, g, model, precision, dedup_leaves, rng_threads, own_stream=lanes > 1 or os.environ.get("AZ_LANE_STREAM") == "1")
                       for i, g in enumerate(share)]
         # The low-latency tower variant takes the whole device per launch (one workgroup per compute unit): right for one
         # lane (256 games: 8.7 ms per move against 11.0), wrong for three or more sharing the card (768 games in 3 lanes:

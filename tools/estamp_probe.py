@@ -42,3 +42,10 @@ for move in (1, 40, 80, 110):
         print("   descents 1-7, median shader cycles each: " + " ".join(str(int(np.median(d2[:, i]))) for i in range(7))
               + "; p90: " + " ".join(str(int(np.percentile(d2[:, i], 90))) for i in range(7)))
         print(f"   start of the descents after the kernel's first stamp: {np.median((t[okf, 4] - t[okf, 0]) / 100.0):.2f} us (real time)")
+    if hasattr(L, "az_debug_einfo"):     # the slowest waves: what each of their first 16 descents did
+        info = np.zeros(n * 16, np.uint32)
+        assert L.az_debug_einfo(info.ctypes.data_as(C.c_void_p), n * 16) == 0
+        info = info.reshape(n, 16)
+        for gi in np.argsort(-tot)[:4]:
+            desc = " ".join(f"{int(v & 255)}{'T' if v & 256 else ''}{'R' if v & 512 else ''}{'+%dL' % ((v >> 12) & 15) if (v >> 12) & 15 else ''}{'+%dm' % ((v >> 16) & 255) if (v >> 16) & 255 else ''}{'/g%d' % ((v >> 24) & 15) if (v >> 24) & 15 else ''}{'/d%d' % (v >> 28) if v >> 28 else ''}" for v in info[gi])
+            print(f"   wave {gi}: {tot[gi]:.1f} us, descents {dt[gi, 4]:.1f} us, expand {dt[gi, 2]:.1f}, backup {dt[gi, 3]:.1f}; path lengths (T terminal, R replayed, +nL levels loaded, +nm nodes from memory, /gn picks the guess did not settle, /dn picks in float64): {desc}")
