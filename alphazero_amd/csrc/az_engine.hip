@@ -89,7 +89,12 @@ struct Dev {
 __device__ unsigned long long g_estamp[4096 * 16];
 #define ESTAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_estamp[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #define ESTAMP_CYCLES(i) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_estamp[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+// what each of the first 16 descents of the last batch did: path length | terminal << 8 | replayed << 9 | level loads << 12 |
+// nodes picked from memory << 16 | picks the guess did not settle << 24 | float64 picks << 28
+__device__ unsigned int g_einfo[4096 * 16];
+#define EINFO(slot, v) do { if (threadIdx.x == 0 && blockIdx.x < 4096 && (slot) < 16) g_einfo[blockIdx.x * 16 + (slot)] = (v); } while (0)
 #else
+#define EINFO(slot, v) do {} while (0)
 #define ESTAMP(i) do {} while (0)
 #define ESTAMP_CYCLES(i) do {} while (0)
 #endif
@@ -708,7 +713,7 @@ __device__ __forceinline__ int lane_pick(const int (&arr)[CPL], int lane, int id
 // does, it is the child the float64 arg-max returns, and the float64 scores are not needed. Before the wave-wide maximum
 // the child picked last is tried alone against the others' upper bounds. Ties and near-ties take the float64 arg-max.
 template <int CPL>
-__device__ __forceinline__ int level_pick(const Dev& d, int lane, Level<CPL>& lv, int pv) {
+__device__ __forceinline__ int level_pick(const Dev& d, int lane, Level<CPL>& lv, int pv, int& dbg) {
     int tslot = pv - lv.pv0;
     if (d.vl > 0.0 ? (tslot < 0 || tslot >= 64) : tslot != 0) { level_table<CPL>(d, lane, lv, pv); tslot = 0; }
     {
@@ -739,6 +744,7 @@ __device__ __forceinline__ int level_pick(const Dev& d, int lane, Level<CPL>& lv
             ci = lv.guess;
         }
         if (total != 1) {
+            dbg += 1;            // the guess did not settle it
             m_lo = wave_max_f32(lo);
             total = 0;
 #pragma unroll
@@ -753,6 +759,7 @@ __device__ __forceinline__ int level_pick(const Dev& d, int lane, Level<CPL>& lv
             return ci;
         }
     }
+    dbg += 16;               // float64 scores needed
     const double pbc = readlane_f64(lv.t_pbc, tslot), sq = readlane_f64(lv.t_sqn, tslot);
     double best = -INFINITY;
     int best_i = 0x7fffffff;
@@ -847,14 +854,21 @@ __device__ __forceinline__ void select_body(const Dev& d, int batch_n, RootCache
         }
     };
     for (int slot = 0; slot < batch_n; ++slot) {
+#ifdef AZ_ESTAMP_FINE   // stamps 12-15: inside the fourth descent
+        if (slot < 4) ESTAMP_CYCLES(8 + slot);
+#define FINE(i) do { if (slot == 3) ESTAMP_CYCLES(i); } while (0)
+#else
         if (slot < 8) ESTAMP_CYCLES(8 + slot);
+#define FINE(i) do {} while (0)
+#endif
         int* path = d.path + ((size_t)g * d.B + slot) * d.max_depth;
         int node = 0, len = 1, nc = rnc, first = rfirst;
         int pv = cached ? rc.r_vis : -1;     // the current node's visit count (-1: in memory)
         int node_cf = 0;                     // child_off of the current node when it was picked from a register level
         int passes = root_passes, moves = root_moves;
         int pick[DC + 1];                    // the child picked at each register level (-1: level not reached)
-        bool failed = false, walking = cached;
+        bool failed = false, walking = cached, short_exit = false;
+        int dbg_loads = 0, dbg_replay = 0, dbg_pick = 0;   // diagnostic builds only
         if (lane == 0) path_lds[0] = 0;
 #pragma unroll
         for (int L = 0; L <= DC; ++L) {
@@ -865,8 +879,9 @@ __device__ __forceinline__ void select_body(const Dev& d, int batch_n, RootCache
             if (L > 0 && lvl.node != node) {
                 level_flush<CPL>(d, nb, lane, lvl);
                 level_load<CPL>(d, nb, lane, node, first, nc, pv, lvl);
+                dbg_loads += 1;
             }
-            const int ci = level_pick<CPL>(d, lane, lvl, pv);
+            const int ci = level_pick<CPL>(d, lane, lvl, pv, dbg_pick);
             if (ci < 0) { failed = true; walking = false; continue; }
             pick[L] = ci;
             const int word = lane_pick<CPL>(lvl.pk, lane, ci);
@@ -878,9 +893,51 @@ __device__ __forceinline__ void select_body(const Dev& d, int batch_n, RootCache
             const int act = (word >> 10) & 1023;
             passes = act == d.np ? passes + 1 : 0;
             moves += 1;
+            if (L == 0 && nc == 0) {
+                // The usual descent ends here, in a child of the root without children: its few results are settled at
+                // once, without the general steps below.
+                const bool terminal1 = passes >= 2 || moves >= 2 * d.np;
+                if (!terminal1 || is_term_code(node_cf)) {
+                    int ref = slot;
+                    if (terminal1) {   // mcts.py:191-192, outcome known from an earlier descent
+                        ref = -1;
+                        n_term += 1;
+                        if (lane == 0) d.term_value[g * d.B + slot] = term_outcome(node_cf);
+                    } else {
+                        if (d.dedup) {
+                            if (node == last_node) ref = last_ref;
+                            else
+                                for (int u = 0; u < n_unique; ++u)
+                                    if (uniq_lds[2 * u + 1] == node) { ref = uniq_lds[2 * u]; break; }
+                        }
+                        if (ref == slot) {
+                            if (lane == 0) { uniq_lds[2 * n_unique] = slot; uniq_lds[2 * n_unique + 1] = node; }
+                            n_unique += 1;
+                        }
+                        last_node = node; last_ref = ref;
+                    }
+                    put_record(slot, 2, ref, node, node);
+                    EINFO(slot, (unsigned)(2 | (terminal1 ? 256 : 0) | (dbg_pick << 24)));
+                    depth_sum += 1;
+                    max_depth = max(max_depth, 1);
+                    if (d.vl > 0.0) {  // mcts.py:196-199
+                        rc.r_vis += 1;
+                        rc.r_vsum -= d.vl;
+#pragma unroll
+                        for (int k = 0; k < CPL; ++k)
+                            if (lane + 64 * k == ci) { lvl.vis[k] += 1; lvl.vsum[k] -= d.vl; lvl.vs32[k] = (float)lvl.vsum[k]; }
+                    }
+                    wave_sync();
+                    short_exit = true;
+                    walking = false;
+                    continue;
+                }
+            }
             if (lane == 0) path_lds[len] = node;
             len += 1;
         }
+        if (short_exit) continue;
+        FINE(12);
         const int reg_len = len;             // path nodes whose statistics are in registers
         if (!failed && (walking || !cached)) {
             // below the register levels (or a root whose children they cannot hold): children read from memory
@@ -944,6 +1001,7 @@ __device__ __forceinline__ void select_body(const Dev& d, int batch_n, RootCache
                     v = sim_outcome<PPL>(d, geo, b, s);
                     if (lane == 0) { tc_node[n_tc] = node; tc_val[n_tc] = v; if (len > 1) d.child_off[nb + node] = term_code(v); }
                     n_tc += 1;
+                    dbg_replay = 1;
                     // the level that holds the node learns the outcome too
 #pragma unroll
                     for (int L = 0; L <= DC; ++L) {
@@ -975,11 +1033,14 @@ __device__ __forceinline__ void select_body(const Dev& d, int batch_n, RootCache
             }
             last_node = node; last_ref = ref;
         }
+        FINE(13);
+        EINFO(slot, (unsigned)(len | (terminal ? 256 : 0) | (dbg_replay << 9) | (dbg_loads << 12) | ((len - reg_len) << 16) | (dbg_pick << 24)));
         const int n1 = len > 1 ? (pick[0] >= 0 ? rfirst + pick[0] : path_lds[1]) : -1;   // the root child on the path
         put_record(slot, len, ref, n1, node);
         depth_sum += len - 1;
         max_depth = max(max_depth, len - 1);
         wave_sync();
+        FINE(14);
         if (d.vl > 0.0) {  // mcts.py:196-199
             if (cached) {
                 rc.r_vis += 1;
@@ -1002,7 +1063,9 @@ __device__ __forceinline__ void select_body(const Dev& d, int batch_n, RootCache
             }
         }
         wave_sync();
+        FINE(15);
     }
+#undef FINE
     ESTAMP(5);
     // the levels go back to memory (the backup that follows the network updates deeper nodes there), the root's to `rc`
 #pragma unroll
@@ -2013,6 +2076,11 @@ int az_mcts_stats(az_engine* e, int64_t* out, void* stream) {
 extern "C" int az_debug_estamps(unsigned long long* out, int words) {
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_estamp), (size_t)words * 8));
+    return AZ_OK;
+}
+extern "C" int az_debug_einfo(unsigned int* out, int words) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_einfo), (size_t)words * 4));
     return AZ_OK;
 }
 #endif
