@@ -853,30 +853,99 @@ __device__ __forceinline__ void select_body(const Dev& d, int batch_n, RootCache
             st_len[slot] = len; st_ref[slot] = ref; st_n1[slot] = n1; st_leaf[slot] = leaf;
         }
     };
-    for (int slot = 0; slot < batch_n; ++slot) {
 #ifdef AZ_ESTAMP_FINE   // stamps 12-15: inside the fourth descent
-        if (slot < 4) ESTAMP_CYCLES(8 + slot);
 #define FINE(i) do { if (slot == 3) ESTAMP_CYCLES(i); } while (0)
 #else
-        if (slot < 8) ESTAMP_CYCLES(8 + slot);
 #define FINE(i) do {} while (0)
 #endif
+    const bool root_open = cached && rnc > 0 && root_passes < 2 && root_moves < 2 * d.np && d.max_depth > 1;
+    int slot = 0;
+    while (slot < batch_n) {
+        // The usual descent ends in a child of the root that has no children: a loop of its own for those, which holds
+        // nothing of the deeper levels' state. It leaves the loop with the root's pick made when a descent goes on.
+        int ci0 = -1, word0 = 0, cf0 = 0;
+        bool failed = false;
+        int dbg_loads = 0, dbg_replay = 0, dbg_pick = 0;   // diagnostic builds only
+        for (; slot < batch_n; ++slot) {
+#ifdef AZ_ESTAMP_FINE
+            if (slot < 4) ESTAMP_CYCLES(8 + slot);
+#else
+            if (slot < 8) ESTAMP_CYCLES(8 + slot);
+#endif
+            ci0 = -1;
+            dbg_pick = 0;
+            if (!root_open) break;
+            Level<CPL>& lvl = lv[0];
+            const int ci = level_pick<CPL>(d, lane, lvl, rc.r_vis, dbg_pick);
+            if (ci < 0) { failed = true; break; }
+            ci0 = ci;
+            word0 = lane_pick<CPL>(lvl.pk, lane, ci);
+            cf0 = lane_pick<CPL>(lvl.cf, lane, ci);
+            if ((word0 & 1023) != 0) break;
+            const int node = rfirst + ci;
+            const int passes1 = ((word0 >> 10) & 1023) == d.np ? root_passes + 1 : 0;
+            const bool terminal1 = passes1 >= 2 || root_moves + 1 >= 2 * d.np;
+            if (terminal1 && !is_term_code(cf0)) break;   // its outcome needs a replay
+            int ref = slot;
+            if (terminal1) {   // mcts.py:191-192, outcome known from an earlier descent
+                ref = -1;
+                n_term += 1;
+                if (lane == 0) d.term_value[g * d.B + slot] = term_outcome(cf0);
+            } else {
+                if (d.dedup) {
+                    if (node == last_node) ref = last_ref;
+                    else
+                        for (int u = 0; u < n_unique; ++u)
+                            if (uniq_lds[2 * u + 1] == node) { ref = uniq_lds[2 * u]; break; }
+                }
+                if (ref == slot) {
+                    if (lane == 0) { uniq_lds[2 * n_unique] = slot; uniq_lds[2 * n_unique + 1] = node; }
+                    n_unique += 1;
+                }
+                last_node = node; last_ref = ref;
+            }
+            put_record(slot, 2, ref, node, node);
+            EINFO(slot, (unsigned)(2 | (terminal1 ? 256 : 0) | (dbg_pick << 24)));
+            depth_sum += 1;
+            max_depth = max(max_depth, 1);
+            if (d.vl > 0.0) {  // mcts.py:196-199
+                rc.r_vis += 1;
+                rc.r_vsum -= d.vl;
+#pragma unroll
+                for (int k = 0; k < CPL; ++k)
+                    if (lane + 64 * k == ci) { lvl.vis[k] += 1; lvl.vsum[k] -= d.vl; lvl.vs32[k] = (float)lvl.vsum[k]; }
+            }
+            wave_sync();
+        }
+        if (slot >= batch_n) break;
+        // ---- the descent of `slot` goes deeper (or ends in a way the loop above does not handle)
         int* path = d.path + ((size_t)g * d.B + slot) * d.max_depth;
         int node = 0, len = 1, nc = rnc, first = rfirst;
         int pv = cached ? rc.r_vis : -1;     // the current node's visit count (-1: in memory)
         int node_cf = 0;                     // child_off of the current node when it was picked from a register level
         int passes = root_passes, moves = root_moves;
         int pick[DC + 1];                    // the child picked at each register level (-1: level not reached)
-        bool failed = false, walking = cached, short_exit = false;
-        int dbg_loads = 0, dbg_replay = 0, dbg_pick = 0;   // diagnostic builds only
+        bool walking = ci0 >= 0;
         if (lane == 0) path_lds[0] = 0;
+        pick[0] = ci0;
+        if (ci0 >= 0) {
+            node_cf = cf0;
+            pv = lane_pick<CPL>(lv[0].vis, lane, ci0);
+            node = rfirst + ci0;
+            nc = word0 & 1023;
+            first = cf0;
+            passes = ((word0 >> 10) & 1023) == d.np ? passes + 1 : 0;
+            moves += 1;
+            if (lane == 0) path_lds[1] = node;
+            len = 2;
+        }
 #pragma unroll
-        for (int L = 0; L <= DC; ++L) {
+        for (int L = 1; L <= DC; ++L) {
             pick[L] = -1;
             if (!walking) continue;
             if (nc == 0 || passes >= 2 || moves >= 2 * d.np || len >= d.max_depth) { walking = false; continue; }
             Level<CPL>& lvl = lv[L];
-            if (L > 0 && lvl.node != node) {
+            if (lvl.node != node) {
                 level_flush<CPL>(d, nb, lane, lvl);
                 level_load<CPL>(d, nb, lane, node, first, nc, pv, lvl);
                 dbg_loads += 1;
@@ -893,50 +962,9 @@ __device__ __forceinline__ void select_body(const Dev& d, int batch_n, RootCache
             const int act = (word >> 10) & 1023;
             passes = act == d.np ? passes + 1 : 0;
             moves += 1;
-            if (L == 0 && nc == 0) {
-                // The usual descent ends here, in a child of the root without children: its few results are settled at
-                // once, without the general steps below.
-                const bool terminal1 = passes >= 2 || moves >= 2 * d.np;
-                if (!terminal1 || is_term_code(node_cf)) {
-                    int ref = slot;
-                    if (terminal1) {   // mcts.py:191-192, outcome known from an earlier descent
-                        ref = -1;
-                        n_term += 1;
-                        if (lane == 0) d.term_value[g * d.B + slot] = term_outcome(node_cf);
-                    } else {
-                        if (d.dedup) {
-                            if (node == last_node) ref = last_ref;
-                            else
-                                for (int u = 0; u < n_unique; ++u)
-                                    if (uniq_lds[2 * u + 1] == node) { ref = uniq_lds[2 * u]; break; }
-                        }
-                        if (ref == slot) {
-                            if (lane == 0) { uniq_lds[2 * n_unique] = slot; uniq_lds[2 * n_unique + 1] = node; }
-                            n_unique += 1;
-                        }
-                        last_node = node; last_ref = ref;
-                    }
-                    put_record(slot, 2, ref, node, node);
-                    EINFO(slot, (unsigned)(2 | (terminal1 ? 256 : 0) | (dbg_pick << 24)));
-                    depth_sum += 1;
-                    max_depth = max(max_depth, 1);
-                    if (d.vl > 0.0) {  // mcts.py:196-199
-                        rc.r_vis += 1;
-                        rc.r_vsum -= d.vl;
-#pragma unroll
-                        for (int k = 0; k < CPL; ++k)
-                            if (lane + 64 * k == ci) { lvl.vis[k] += 1; lvl.vsum[k] -= d.vl; lvl.vs32[k] = (float)lvl.vsum[k]; }
-                    }
-                    wave_sync();
-                    short_exit = true;
-                    walking = false;
-                    continue;
-                }
-            }
             if (lane == 0) path_lds[len] = node;
             len += 1;
         }
-        if (short_exit) continue;
         FINE(12);
         const int reg_len = len;             // path nodes whose statistics are in registers
         if (!failed && (walking || !cached)) {
@@ -1064,6 +1092,7 @@ __device__ __forceinline__ void select_body(const Dev& d, int batch_n, RootCache
         }
         wave_sync();
         FINE(15);
+        slot += 1;
     }
 #undef FINE
     ESTAMP(5);
@@ -1095,14 +1124,13 @@ __device__ __forceinline__ void select_body(const Dev& d, int batch_n, RootCache
     if (lane == 0) {
         brec[0] = n_unique; brec[1] = 0; brec[2] = rnc; brec[3] = rfirst;
         d.n_unique[g] = n_unique;
-        // per-game counters, nobody else's: atomics without a result, so that the wave does not wait for a read-modify-write
-        unsigned long long* gs = (unsigned long long*)(d.gstats + (size_t)g * 8);
-        atomicAdd(&gs[ST_DEPTH_SUM], (unsigned long long)depth_sum);
-        atomicMax((long long*)&gs[ST_MAX_DEPTH], (long long)max_depth);
-        atomicAdd(&gs[ST_TERMINAL], (unsigned long long)n_term);
-        atomicAdd(&gs[ST_SIMS], (unsigned long long)batch_n);
-        atomicAdd(&gs[ST_ROWS_RAW], (unsigned long long)(batch_n - n_term));
-        atomicAdd(&gs[ST_ROWS], (unsigned long long)n_unique);
+        long long* gs = d.gstats + (size_t)g * 8;
+        gs[ST_DEPTH_SUM] += depth_sum;
+        gs[ST_MAX_DEPTH] = max(gs[ST_MAX_DEPTH], (long long)max_depth);
+        gs[ST_TERMINAL] += n_term;
+        gs[ST_SIMS] += batch_n;
+        gs[ST_ROWS_RAW] += batch_n - n_term;
+        gs[ST_ROWS] += n_unique;
     }
     ESTAMP(6);
     if (rows_ctr) {
