@@ -651,7 +651,6 @@ struct Level {
     int node, n, first;       // whose children (-1: none), how many, index of the first
     int pv0;                  // visit count of the node that lane 0's exploration-table entries belong to
     int guess;                // the child picked last (with virtual loss, usually picked again)
-    bool dirty;               // vis / vsum differ from memory
     double t_pbc, t_sqn;      // lane i: exploration-table entries for pv0 + i visits of the node (pv0 without virtual loss)
     float t_pbc32, t_sqn32;
     double prior[CPL], vsum[CPL];
@@ -659,31 +658,36 @@ struct Level {
     int vis[CPL], pk[CPL], cf[CPL];   // cf: child_off of the child (first grandchild, or the outcome code of a terminal child)
 };
 
-template <int CPL>
+// The wave-uniform fields of the levels below the root are kept in vector registers (COLD): scalar registers are short in
+// these kernels, and a level's fields are only needed by a descent that reaches it.
+__device__ __forceinline__ int to_vgpr(int x) { asm volatile("" : "+v"(x)); return x; }
+template <bool COLD> __device__ __forceinline__ int cold_set(int x) { return COLD ? to_vgpr(x) : x; }
+template <bool COLD> __device__ __forceinline__ int cold_get(int x) { return COLD ? __builtin_amdgcn_readfirstlane(x) : x; }
+
+template <int CPL, bool COLD>
 __device__ __forceinline__ void level_table(const Dev& d, int lane, Level<CPL>& lv, int pv) {
     const int t_idx = min(pv + (d.vl > 0.0 ? lane : 0), d.tab_len - 1);
-    lv.pv0 = pv;
+    lv.pv0 = cold_set<COLD>(pv);
     lv.t_pbc = d.pbc[t_idx]; lv.t_sqn = d.sqn[t_idx];
     lv.t_pbc32 = (float)lv.t_pbc; lv.t_sqn32 = (float)lv.t_sqn;
 }
 
 template <int CPL>
 __device__ __forceinline__ void level_flush(const Dev& d, size_t nb, int lane, Level<CPL>& lv) {
-    if (lv.node >= 0 && lv.dirty) {
+    if (cold_get<true>(lv.node) >= 0) {
 #pragma unroll
         for (int k = 0; k < CPL; ++k) {
             const int i = lane + 64 * k;
             if (i < lv.n) { d.visits[nb + lv.first + i] = lv.vis[k]; d.vsum[nb + lv.first + i] = lv.vsum[k]; }
         }
     }
-    lv.dirty = false;
 }
 
 // pv: the node's visit count now.
 template <int CPL>
 __device__ __forceinline__ void level_load(const Dev& d, size_t nb, int lane, int node, int first, int n, int pv, Level<CPL>& lv) {
-    lv.node = node; lv.first = first; lv.n = n; lv.guess = -1; lv.dirty = false;
-    level_table<CPL>(d, lane, lv, pv);
+    lv.node = to_vgpr(node); lv.first = to_vgpr(first); lv.n = to_vgpr(n); lv.guess = to_vgpr(-1);
+    level_table<CPL, true>(d, lane, lv, pv);
 #pragma unroll
     for (int k = 0; k < CPL; ++k) {
         const int i = lane + 64 * k;
@@ -712,10 +716,11 @@ __device__ __forceinline__ int lane_pick(const int (&arr)[CPL], int lane, int id
 // 1.4e-6 (|u| + |q|); e takes 4e-6). Only children with sc + e >= max(sc - e) can hold the float64 maximum; when exactly one
 // does, it is the child the float64 arg-max returns, and the float64 scores are not needed. Before the wave-wide maximum
 // the child picked last is tried alone against the others' upper bounds. Ties and near-ties take the float64 arg-max.
-template <int CPL>
+template <int CPL, bool COLD>
 __device__ __forceinline__ int level_pick(const Dev& d, int lane, Level<CPL>& lv, int pv, int& dbg) {
-    int tslot = pv - lv.pv0;
-    if (d.vl > 0.0 ? (tslot < 0 || tslot >= 64) : tslot != 0) { level_table<CPL>(d, lane, lv, pv); tslot = 0; }
+    int tslot = cold_get<COLD>(pv - lv.pv0);
+    const int guess = cold_get<COLD>(lv.guess);
+    if (d.vl > 0.0 ? (tslot < 0 || tslot >= 64) : tslot != 0) { level_table<CPL, COLD>(d, lane, lv, pv); tslot = 0; }
     {
         const float pbc32 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lv.t_pbc32), tslot));
         const float sq32 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lv.t_sqn32), tslot));
@@ -734,14 +739,14 @@ __device__ __forceinline__ int level_pick(const Dev& d, int lane, Level<CPL>& lv
         }
         float m_lo = -INFINITY;
         int total = 0, ci = 0;
-        if (lv.guess >= 0) {
+        if (guess >= 0) {
             float lo_g = -INFINITY;
 #pragma unroll
-            for (int k = 0; k < CPL; ++k) lo_g = lane + 64 * k == lv.guess ? lo_k[k] : lo_g;
-            m_lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lo_g), lv.guess & 63));
+            for (int k = 0; k < CPL; ++k) lo_g = lane + 64 * k == guess ? lo_k[k] : lo_g;
+            m_lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lo_g), guess & 63));
 #pragma unroll
             for (int k = 0; k < CPL; ++k) total += __popcll(__ballot(hi[k] >= m_lo));
-            ci = lv.guess;
+            ci = guess;
         }
         if (total != 1) {
             dbg += 1;            // the guess did not settle it
@@ -755,7 +760,7 @@ __device__ __forceinline__ int level_pick(const Dev& d, int lane, Level<CPL>& lv
             }
         }
         if (total == 1 && m_lo > -1e17f) {   // (scores at or below -1e18 never win: mcts.py:100, :109)
-            lv.guess = ci;
+            lv.guess = cold_set<COLD>(ci);
             return ci;
         }
     }
@@ -778,7 +783,7 @@ __device__ __forceinline__ int level_pick(const Dev& d, int lane, Level<CPL>& lv
     }
     wave_argmax(best, best_i);
     if (best_i == 0x7fffffff) return -1;   // mcts.py:114-115
-    lv.guess = best_i;
+    lv.guess = cold_set<COLD>(best_i);
     return best_i;
 }
 
@@ -830,7 +835,7 @@ __device__ __forceinline__ void select_body(const Dev& d, int batch_n, RootCache
     Level<CPL> lv[DC + 1];
     {
         Level<CPL>& L0 = lv[0];
-        L0.node = 0; L0.n = cached ? rnc : 0; L0.first = rfirst; L0.pv0 = t_base; L0.guess = -1; L0.dirty = false;
+        L0.node = 0; L0.n = cached ? rnc : 0; L0.first = rfirst; L0.pv0 = t_base; L0.guess = -1;
         L0.t_pbc = t_pbc; L0.t_sqn = t_sqn; L0.t_pbc32 = (float)t_pbc; L0.t_sqn32 = (float)t_sqn;
 #pragma unroll
         for (int k = 0; k < CPL; ++k) {
@@ -840,7 +845,7 @@ __device__ __forceinline__ void select_body(const Dev& d, int batch_n, RootCache
         }
     }
 #pragma unroll
-    for (int L = 1; L <= DC; ++L) { lv[L].node = -1; lv[L].n = 0; lv[L].dirty = false; lv[L].guess = -1; }
+    for (int L = 1; L <= DC; ++L) { lv[L].node = to_vgpr(-1); lv[L].n = to_vgpr(0); lv[L].first = to_vgpr(0); lv[L].guess = to_vgpr(-1); }
 
     int last_node = -1, last_ref = -1;   // the distinct leaf found last (most descents of a batch end in it again)
     // Per-descent results: lane s keeps those of slot s in registers (slots from 64 on: LDS) until they are written out
@@ -876,7 +881,7 @@ __device__ __forceinline__ void select_body(const Dev& d, int batch_n, RootCache
             dbg_pick = 0;
             if (!root_open) break;
             Level<CPL>& lvl = lv[0];
-            const int ci = level_pick<CPL>(d, lane, lvl, rc.r_vis, dbg_pick);
+            const int ci = level_pick<CPL, false>(d, lane, lvl, rc.r_vis, dbg_pick);
             if (ci < 0) { failed = true; break; }
             ci0 = ci;
             word0 = lane_pick<CPL>(lvl.pk, lane, ci);
@@ -945,18 +950,18 @@ __device__ __forceinline__ void select_body(const Dev& d, int batch_n, RootCache
             if (!walking) continue;
             if (nc == 0 || passes >= 2 || moves >= 2 * d.np || len >= d.max_depth) { walking = false; continue; }
             Level<CPL>& lvl = lv[L];
-            if (lvl.node != node) {
+            if (cold_get<true>(lvl.node) != node) {
                 level_flush<CPL>(d, nb, lane, lvl);
                 level_load<CPL>(d, nb, lane, node, first, nc, pv, lvl);
                 dbg_loads += 1;
             }
-            const int ci = level_pick<CPL>(d, lane, lvl, pv, dbg_pick);
+            const int ci = level_pick<CPL, true>(d, lane, lvl, pv, dbg_pick);
             if (ci < 0) { failed = true; walking = false; continue; }
             pick[L] = ci;
             const int word = lane_pick<CPL>(lvl.pk, lane, ci);
             node_cf = lane_pick<CPL>(lvl.cf, lane, ci);
             pv = lane_pick<CPL>(lvl.vis, lane, ci);
-            node = lvl.first + ci;
+            node = cold_get<true>(lvl.first) + ci;
             nc = word & 1023;
             first = node_cf;
             const int act = (word >> 10) & 1023;
@@ -1080,7 +1085,6 @@ __device__ __forceinline__ void select_body(const Dev& d, int batch_n, RootCache
 #pragma unroll
                         for (int k = 0; k < CPL; ++k)
                             if (lane + 64 * k == pick[L]) { lvl.vis[k] += 1; lvl.vsum[k] -= d.vl; lvl.vs32[k] = (float)lvl.vsum[k]; }
-                        lvl.dirty = true;
                     }
                 }
             }

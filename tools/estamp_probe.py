@@ -48,4 +48,7 @@ for move in (1, 40, 80, 110):
         info = info.reshape(n, 16)
         for gi in np.argsort(-tot)[:4]:
             desc = " ".join(f"{int(v & 255)}{'T' if v & 256 else ''}{'R' if v & 512 else ''}{'+%dL' % ((v >> 12) & 15) if (v >> 12) & 15 else ''}{'+%dm' % ((v >> 16) & 255) if (v >> 16) & 255 else ''}{'/g%d' % ((v >> 24) & 15) if (v >> 24) & 15 else ''}{'/d%d' % (v >> 28) if v >> 28 else ''}" for v in info[gi])
+            if os.environ.get("AZ_FINE") == "1":    # -DAZ_ESTAMP_FINE build: shader cycles inside the fourth descent
+                ff = f[gi]
+                print(f"   wave {gi}: fourth descent: levels {ff[4] - ff[3]}, leaf kind {ff[5] - ff[4]}, record {ff[6] - ff[5]}, virtual loss {ff[7] - ff[6]} cycles")
             print(f"   wave {gi}: {tot[gi]:.1f} us, descents {dt[gi, 4]:.1f} us, expand {dt[gi, 2]:.1f}, backup {dt[gi, 3]:.1f}; path lengths (T terminal, R replayed, +nL levels loaded, +nm nodes from memory, /gn picks the guess did not settle, /dn picks in float64): {desc}")
