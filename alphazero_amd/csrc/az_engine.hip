@@ -788,7 +788,9 @@ __device__ __forceinline__ int level_pick(const Dev& d, int lane, Level<CPL>& lv
 }
 
 // Levels below the root that a wave keeps in registers (the root's children always are): leaves down to depth
-// kDeepLevels + 1 are reached without memory accesses once their path has been walked in the batch.
+// DeepLevels + 1 are reached without memory accesses once their path has been walked in the batch. The "wide" kernels keep
+// none and fit four waves on a SIMD (128 registers): with more games than the chip holds waves of the regular kernels
+// (two per SIMD), what counts is how many waves run at once, not how long one takes. Same results either way.
 #ifdef AZ_DEEP_LEVELS   // diagnostic builds
 template <int CPL> struct DeepLevels { static constexpr int v = AZ_DEEP_LEVELS; };
 #else
@@ -797,11 +799,10 @@ template <int CPL> struct DeepLevels { static constexpr int v = CPL <= 2 ? 3 : (
 
 // mcts.py:181-199: batch_n descents for game blockIdx.x. `rc` holds the root's statistics (rc_load) and is left updated,
 // not stored. rows_ctr: null (the row scan kernel assigns the rows), or the counter this batch's rows are allotted from.
-template <int PPL>
+template <int PPL, int DC>
 __device__ __forceinline__ void select_body(const Dev& d, int batch_n, RootCache<Apl<PPL>::v>& rc, int root_passes, int root_moves,
                                             double t_pbc, double t_sqn, int t_base, int* rows_ctr) {
     constexpr int CPL = Apl<PPL>::v;
-    constexpr int DC = DeepLevels<CPL>::v;
     __shared__ BoardLds<PPL> b;
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
     uint64_t* seen_lds = (uint64_t*)dyn;
@@ -871,6 +872,7 @@ __device__ __forceinline__ void select_body(const Dev& d, int batch_n, RootCache
         int ci0 = -1, word0 = 0, cf0 = 0;
         bool failed = false;
         int dbg_loads = 0, dbg_replay = 0, dbg_pick = 0;   // diagnostic builds only
+        (void)dbg_loads; (void)dbg_replay;
         for (; slot < batch_n; ++slot) {
 #ifdef AZ_ESTAMP_FINE
             if (slot < 4) ESTAMP_CYCLES(8 + slot);
@@ -1145,8 +1147,8 @@ __device__ __forceinline__ void select_body(const Dev& d, int batch_n, RootCache
 }
 
 // The first batch of a search (the later ones run behind the previous batch's expansion in k_expand_select).
-template <int PPL>
-__global__ __launch_bounds__(64) void k_select(Dev d, int batch_n, int* rows_ctr, int visits_hint) {
+template <int PPL, int DC>
+__device__ __forceinline__ void select_kernel(const Dev& d, int batch_n, int* rows_ctr, int visits_hint) {
     const int g = blockIdx.x, lane = threadIdx.x;
     if (!d.active[g]) { if (lane == 0) { d.n_unique[g] = 0; d.brec[(size_t)g * brec_words(d)] = 0; } return; }
     const int t_idx = min(visits_hint + (d.vl > 0.0 ? lane : 0), d.tab_len - 1);
@@ -1155,8 +1157,16 @@ __global__ __launch_bounds__(64) void k_select(Dev d, int batch_n, int* rows_ctr
     const size_t nb = (size_t)g * d.max_nodes;
     RootCache<Apl<PPL>::v> rc;
     rc_load<Apl<PPL>::v>(d, nb, lane, d.n_child[nb], d.child_off[nb], rc);
-    select_body<PPL>(d, batch_n, rc, passes, moves, t_pbc, t_sqn, visits_hint, rows_ctr);
+    select_body<PPL, DC>(d, batch_n, rc, passes, moves, t_pbc, t_sqn, visits_hint, rows_ctr);
     rc_store<Apl<PPL>::v>(d, nb, lane, rc);
+}
+template <int PPL>
+__global__ __launch_bounds__(64) void k_select(Dev d, int batch_n, int* rows_ctr, int visits_hint) {
+    select_kernel<PPL, DeepLevels<Apl<PPL>::v>::v>(d, batch_n, rows_ctr, visits_hint);
+}
+template <int PPL>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_select_wide(Dev d, int batch_n, int* rows_ctr, int visits_hint) {
+    select_kernel<PPL, 0>(d, batch_n, rows_ctr, visits_hint);
 }
 
 // Leaf gather: one wave per pending row replays the row's path from its game's root and writes the
@@ -1567,9 +1577,9 @@ __global__ __launch_bounds__(64) void k_expand_backup(Dev d, const float* logits
 // two nothing crosses games (the leaf gather and the network sit between a select and its expand), so a search enqueued
 // as a whole saves a launch per round, the root's statistics stay in registers from the backup through the descents, and
 // the descents' rows are allotted from a counter (rows_ctr) instead of a scan over the games.
-template <int PPL>
-__global__ __launch_bounds__(64) void k_expand_select(Dev d, const float* logits, const float* values, int batch_prev, double* priors_out, int batch_next,
-                                                      int* rows_ctr, int visits_hint) {
+template <int PPL, int DC>
+__device__ __forceinline__ void expand_select_kernel(const Dev& d, const float* logits, const float* values, int batch_prev, double* priors_out,
+                                                     int batch_next, int* rows_ctr, int visits_hint) {
     const int g = blockIdx.x, lane = threadIdx.x;
     if (!d.active[g]) { if (lane == 0) d.n_unique[g] = 0; return; }
     // independent of the expansion: the exploration-table entries of the coming descents, the root's pass / move counters
@@ -1582,9 +1592,19 @@ __global__ __launch_bounds__(64) void k_expand_select(Dev d, const float* logits
     __threadfence_block();
     __syncthreads();   // deeper statistics written by the backup are read by the descents; the two phases share the LDS
     ESTAMP(4);
-    select_body<PPL>(d, batch_next, rc, passes, moves, t_pbc, t_sqn, visits_hint, rows_ctr);
+    select_body<PPL, DC>(d, batch_next, rc, passes, moves, t_pbc, t_sqn, visits_hint, rows_ctr);
     rc_store<Apl<PPL>::v>(d, (size_t)g * d.max_nodes, lane, rc);
     ESTAMP(7);
+}
+template <int PPL>
+__global__ __launch_bounds__(64) void k_expand_select(Dev d, const float* logits, const float* values, int batch_prev, double* priors_out, int batch_next,
+                                                      int* rows_ctr, int visits_hint) {
+    expand_select_kernel<PPL, DeepLevels<Apl<PPL>::v>::v>(d, logits, values, batch_prev, priors_out, batch_next, rows_ctr, visits_hint);
+}
+template <int PPL>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_expand_select_wide(Dev d, const float* logits, const float* values, int batch_prev,
+                                                                                                    double* priors_out, int batch_next, int* rows_ctr, int visits_hint) {
+    expand_select_kernel<PPL, 0>(d, logits, values, batch_prev, priors_out, batch_next, rows_ctr, visits_hint);
 }
 
 __global__ __launch_bounds__(64) void k_root_counts(Dev d, int* counts) {
@@ -1637,6 +1657,7 @@ struct az_engine {
     az_config cfg;
     Dev d;
     int ppl;
+    int simds = 1024;               // SIMDs of the device (4 per CU)
     int phase = PH_IDLE;
     int sims_done = 0, batch_n = 0;
     int pending_rows = 0;
@@ -1702,6 +1723,10 @@ int az_engine_create(const az_config* c, az_engine** out) {
     d.dedup = c->dedup_leaves ? 1 : 0;
     d.komi = c->komi; d.eps = c->dirichlet_eps; d.one_minus_eps = 1 - c->dirichlet_eps;
     e->ppl = d.np <= 64 ? 1 : d.np <= 128 ? 2 : d.np <= 192 ? 3 : 6;
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && cus > 0) e->simds = 4 * cus;
+    }
     {   // what the search kernels are laid out for: actions per lane (Apl), the pairwise-sum pieces, the packed child word
         const int apl = e->ppl <= 2 ? 2 : e->ppl;
         if (d.A > 64 * apl || d.A > 504 || d.A > 1023) { delete e; return fail(AZ_ERR_ARG, "action count above the search kernels' layout"); }
@@ -1851,6 +1876,9 @@ int az_mcts_begin(az_engine* e, const uint8_t* enable, void* stream) {
 
 // dynamic LDS of the descents: seen keys, then path, uniq pairs, staged len / ref / root child / leaf / path[8], terminal-leaf
 // cache (node, value)
+// More games than the chip holds waves of the regular descent kernels (two per SIMD): the four-per-SIMD kernels.
+// (not for boards above 13x13, whose six children per lane do not fit 128 registers)
+static bool wide_search(const az_engine* e) { return e->d.G > 2 * e->simds && e->ppl <= 3; }
 static size_t select_shmem(const az_engine* e) {
     return seen_bytes(e) + ((size_t)e->d.max_depth + (2 + 4 + 8 + 1 + 2) * (size_t)e->d.B) * 4;
 }
@@ -1861,7 +1889,8 @@ int az_mcts_select(az_engine* e, void* stream) {
     if (!e) return fail(AZ_ERR_ARG, "null engine");
     if (e->phase != PH_NEED_SELECT) return fail(AZ_ERR_STATE, "az_mcts_select: no batch to select (expand the pending rows first)");
     e->batch_n = std::min(e->d.B, e->d.sims - e->sims_done);
-    DISPATCH_PPL(e, k_select, e->d.G, select_shmem(e), stream, e->d, e->batch_n, (int*)nullptr, e->sims_done);
+    if (wide_search(e)) DISPATCH_PPL(e, k_select_wide, e->d.G, select_shmem(e), stream, e->d, e->batch_n, (int*)nullptr, e->sims_done);
+    else DISPATCH_PPL(e, k_select, e->d.G, select_shmem(e), stream, e->d, e->batch_n, (int*)nullptr, e->sims_done);
     hipLaunchKernelGGL(k_scan_rows, dim3(1), dim3(1024), 0, (hipStream_t)stream, e->d, 0);
     e->phase = PH_SELECTED;
     e->rows_known = false;
@@ -1997,7 +2026,8 @@ static int enqueue_rounds(az_engine* e, az_net* net, void* feat, int32_t layout,
     const size_t leaf_shmem = seen_bytes(e) + (size_t)e->d.H * e->d.npad;
     int parity = 0;
     e->batch_n = std::min(e->d.B, e->d.sims - e->sims_done);
-    DISPATCH_PPL(e, k_select, e->d.G, select_shmem(e), stream, e->d, e->batch_n, e->d.ctl + 4 + parity, e->sims_done);
+    if (wide_search(e)) DISPATCH_PPL(e, k_select_wide, e->d.G, select_shmem(e), stream, e->d, e->batch_n, e->d.ctl + 4 + parity, e->sims_done);
+    else DISPATCH_PPL(e, k_select, e->d.G, select_shmem(e), stream, e->d, e->batch_n, e->d.ctl + 4 + parity, e->sims_done);
     e->phase = PH_SELECTED;
     e->rows_known = false;
     for (;;) {
@@ -2015,8 +2045,12 @@ static int enqueue_rounds(az_engine* e, az_net* net, void* feat, int32_t layout,
         const int batch_next = std::min(e->d.B, left);
         const size_t shmem = std::max(expand_shmem(e), select_shmem(e));
         parity ^= 1;
-        DISPATCH_PPL(e, k_expand_select, e->d.G, shmem, stream, e->d, (const float*)logits, (const float*)values, e->batch_n, e->last_priors, batch_next,
-                     e->d.ctl + 4 + parity, e->sims_done + e->batch_n);
+        if (wide_search(e))
+            DISPATCH_PPL(e, k_expand_select_wide, e->d.G, shmem, stream, e->d, (const float*)logits, (const float*)values, e->batch_n, e->last_priors,
+                         batch_next, e->d.ctl + 4 + parity, e->sims_done + e->batch_n);
+        else
+            DISPATCH_PPL(e, k_expand_select, e->d.G, shmem, stream, e->d, (const float*)logits, (const float*)values, e->batch_n, e->last_priors,
+                         batch_next, e->d.ctl + 4 + parity, e->sims_done + e->batch_n);
         rc = check_launch("k_expand_select");
         if (rc != AZ_OK) return rc;
         e->sims_done += e->batch_n;

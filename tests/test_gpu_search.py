@@ -124,3 +124,78 @@ def test_full_size_search_dedup_invariance():
     assert (va.sum(axis=1) == 256).all()
     assert sa["sims"] == sb["sims"] == G * 256 and sb["rows"] == sb["rows_raw"] == G * 256 - sb["terminal"]
     assert sa["rows"] < sb["rows"] and sa["rows_raw"] == sb["rows_raw"]
+
+
+def test_wide_descent_kernels_agree_with_the_regular_ones(oracle_lib):
+    """More games than the chip holds waves of the regular descent kernels switch the engine to the kernels that keep no
+    levels below the root in registers: same visits and root values as the same roots searched in two halves by the
+    regular kernels, and as the oracle's search on a sample of them. Roots late in random games, so that the trees go deep."""
+    import stubnets
+    n, sims, B, K, G = 9, 64, 8, 0, 2304
+    rng = np.random.RandomState(11)
+    plies = [rng.randint(0, n * n, size=G).astype(np.int32) for _ in range(56)]
+    noise_seed = 500
+
+    def run(lo, hi):
+        eng = _engine(board_size=n, games=hi - lo, num_simulations=sims, inference_batch_size=B, topk_expand=K)
+        for a in plies:
+            eng.play(a[lo:hi], raise_on_illegal=False)     # occupied or illegal points are skipped, the same way everywhere
+        rngs = [np.random.RandomState(noise_seed + g) for g in range(lo, hi)]
+        visits, rv = eng.run_search(stub_evaluator("hash"), add_noise=True, rngs=rngs)
+        st = eng.stats()
+        out = visits.cpu().numpy(), rv.cpu().numpy(), st
+        eng.close()
+        return out
+
+    va, ra, sa = run(0, G)
+    vb0, rb0, sb0 = run(0, G // 2)
+    vb1, rb1, sb1 = run(G // 2, G)
+    assert np.array_equal(va, np.concatenate([vb0, vb1])) and np.array_equal(ra, np.concatenate([rb0, rb1]))
+    assert sa["max_depth"] >= 3 and sa["max_depth"] == max(sb0["max_depth"], sb1["max_depth"])
+    assert sa["depth_sum"] == sb0["depth_sum"] + sb1["depth_sum"] and sa["terminal"] == sb0["terminal"] + sb1["terminal"]
+    for g in (0, 1, 700, 1151, 1152, 2303):
+        st = oracle_lib.OracleState.new_game(n, 5.5, 8)
+        for a in plies:
+            if st.is_terminal():
+                break
+            if st.legal_mask()[a[g]]:
+                st.play_inplace(int(a[g]))
+        if st.is_terminal():
+            continue
+        m = oracle_lib.OracleMCTS(lambda x: stubnets.stub_eval("hash", x), board_size=n, num_simulations=sims,
+                                  inference_batch_size=B, topk_expand=K)
+        ov, orv = m.search(st, True, np.random.RandomState(noise_seed + g))
+        assert np.array_equal(va[g].astype(np.float64), ov) and ra[g] == orv, f"game {g}"
+
+
+def test_wide_round_kernels_agree_with_the_regular_ones():
+    """The same for searches enqueued as a whole with the native network (expansion + backup + next descents in one
+    launch): 2304 games in one engine against the two halves, bit for bit."""
+    import torch
+    from alphazero_amd.engine import Engine
+    from alphazero_amd.model import AlphaZeroNet
+    torch.manual_seed(1)
+    net = AlphaZeroNet(channels=64, num_blocks=2).eval().cuda().native("bf16")
+    n, sims, B, K, G = 9, 256, 16, 6, 2304     # six children per node and 16 batches: the trees go deep
+    rng = np.random.RandomState(12)
+    plies = [rng.randint(0, n * n, size=G).astype(np.int32) for _ in range(60)]
+
+    def run(lo, hi):
+        eng = Engine(board_size=n, games=hi - lo, num_simulations=sims, inference_batch_size=B, topk_expand=K)
+        for a in plies:
+            eng.play(a[lo:hi], raise_on_illegal=False)
+        rngs = [np.random.RandomState(900 + g) for g in range(lo, hi)]
+        visits, rv = eng.run_search(net.forward, add_noise=True, rngs=rngs, layout=net.layout)
+        st = eng.stats()
+        out = visits.cpu().numpy(), rv.cpu().numpy(), st
+        eng.close()
+        return out
+
+    va, ra, sa = run(0, G)
+    vb0, rb0, sb0 = run(0, G // 2)
+    vb1, rb1, sb1 = run(G // 2, G)
+    assert np.array_equal(va, np.concatenate([vb0, vb1])) and np.array_equal(ra, np.concatenate([rb0, rb1]))
+    assert (va.sum(axis=1) == sims).all()
+    for k in ("sims", "rows", "rows_raw", "depth_sum", "terminal"):
+        assert sa[k] == sb0[k] + sb1[k], k
+    assert sa["max_depth"] >= 2
