@@ -170,32 +170,35 @@ def test_wide_descent_kernels_agree_with_the_regular_ones(oracle_lib):
 
 def test_wide_round_kernels_agree_with_the_regular_ones():
     """The same for searches enqueued as a whole with the native network (expansion + backup + next descents in one
-    launch): 2304 games in one engine against the two halves, bit for bit."""
+    launch): 2304 games in one engine against the two halves, and against the step-by-step search (one launch per
+    phase), bit for bit."""
     import torch
     from alphazero_amd.engine import Engine
     from alphazero_amd.model import AlphaZeroNet
     torch.manual_seed(1)
     net = AlphaZeroNet(channels=64, num_blocks=2).eval().cuda().native("bf16")
-    n, sims, B, K, G = 9, 256, 16, 6, 2304     # six children per node and 16 batches: the trees go deep
+    n, sims, B, K, G = 9, 256, 16, 3, 2304     # three children per node and 16 batches: the trees go deep
     rng = np.random.RandomState(12)
     plies = [rng.randint(0, n * n, size=G).astype(np.int32) for _ in range(60)]
 
-    def run(lo, hi):
+    def run(lo, hi, rounds):
         eng = Engine(board_size=n, games=hi - lo, num_simulations=sims, inference_batch_size=B, topk_expand=K)
         for a in plies:
             eng.play(a[lo:hi], raise_on_illegal=False)
         rngs = [np.random.RandomState(900 + g) for g in range(lo, hi)]
-        visits, rv = eng.run_search(net.forward, add_noise=True, rngs=rngs, layout=net.layout)
+        visits, rv = eng.run_search(net.forward, add_noise=True, rngs=rngs, layout=net.layout, native_net=net if rounds else None)
         st = eng.stats()
         out = visits.cpu().numpy(), rv.cpu().numpy(), st
         eng.close()
         return out
 
-    va, ra, sa = run(0, G)
-    vb0, rb0, sb0 = run(0, G // 2)
-    vb1, rb1, sb1 = run(G // 2, G)
+    va, ra, sa = run(0, G, True)
+    vb0, rb0, sb0 = run(0, G // 2, True)
+    vb1, rb1, sb1 = run(G // 2, G, True)
+    vc, rc, sc = run(0, G, False)
     assert np.array_equal(va, np.concatenate([vb0, vb1])) and np.array_equal(ra, np.concatenate([rb0, rb1]))
+    assert np.array_equal(va, vc) and np.array_equal(ra, rc)
     assert (va.sum(axis=1) == sims).all()
     for k in ("sims", "rows", "rows_raw", "depth_sum", "terminal"):
-        assert sa[k] == sb0[k] + sb1[k], k
-    assert sa["max_depth"] >= 2
+        assert sa[k] == sb0[k] + sb1[k] == sc[k], k
+    assert sa["max_depth"] >= 3, sa
