@@ -1524,8 +1524,27 @@ __device__ __forceinline__ void expand_backup_body(const Dev& d, const float* lo
     if (STAMPED) ESTAMP(3);
     double* vsum = d.vsum + nb;
     int* visits = d.visits + nb;
-    // Deeper nodes than the root's children are updated in memory.
     const bool vl_on = d.vl > 0.0;
+    // Nodes below the root's children are updated in memory. When the batch's deep path nodes fit the LDS table below, every
+    // distinct node is loaded once, takes the updates of all slots that pass through it in slot order (the order and the
+    // operations of mcts.py:205-218 per node; different nodes do not interact) and is stored once; else slot by slot.
+    int* e_node = (int*)p_lds;                      // the expansion's scratch is free now: [2 A] doubles
+    const int ecap = (2 * d.A * 8 - 8) / 12;
+    double* e_val = (double*)(e_node + ((ecap + 1) & ~1));
+    int my_cnt = 0, my_off = 0, n_deep = 0;
+    bool table = cached && batch_n <= 64;
+    if (table) {
+        if (lane < batch_n) my_cnt = max(0, (r_len[lane] & 0xffff) - 2);
+        int incl = my_cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int up = __shfl_up(incl, o);
+            if (lane >= o) incl += up;
+        }
+        my_off = incl - my_cnt;
+        n_deep = __builtin_amdgcn_readlane(incl, 63);
+        table = n_deep <= ecap;
+    }
     for (int slot = 0; slot < batch_n; ++slot) {
         const double value = s_val[slot];
         const int len = r_len[slot] & 0xffff;
@@ -1548,7 +1567,7 @@ __device__ __forceinline__ void expand_backup_body(const Dev& d, const float* lo
                     }
             }
         }
-        if (!cached || len > 2) {
+        if (!table && (!cached || len > 2)) {
             const int* path = d.path + ((size_t)g * d.B + slot) * d.max_depth;
             for (int i = (cached ? 2 : 0) + lane; i < len; i += 64) {
                 const int pn = path[i];
@@ -1561,6 +1580,39 @@ __device__ __forceinline__ void expand_backup_body(const Dev& d, const float* lo
             }
             __threadfence_block();
             __syncthreads();
+        }
+    }
+    if (table && n_deep > 0) {
+        if (my_cnt > 0) {   // lane = slot: its path nodes from index 2 on, with the value each takes
+            const int len = r_len[lane] & 0xffff;
+            const double value = s_val[lane];
+            const int* path = d.path + ((size_t)g * d.B + lane) * d.max_depth;
+            for (int i = 2; i < len; ++i) {
+                e_node[my_off + i - 2] = path[i];
+                e_val[my_off + i - 2] = ((len - 1 - i) & 1) ? -value : value;
+            }
+        }
+        __syncthreads();
+        for (int e0 = 0; e0 < n_deep; e0 += 64) {
+            const int e = e0 + lane;
+            if (e < n_deep) {
+                const int pn = e_node[e];
+                bool first = true;
+                for (int e2 = 0; e2 < e; ++e2) first = first && e_node[e2] != pn;
+                if (first) {   // the node's first appearance: this lane applies all of them
+                    int vc = visits[pn];
+                    double vs = vsum[pn];
+                    for (int e2 = e; e2 < n_deep; ++e2) {
+                        if (e_node[e2] == pn) {
+                            if (vl_on) { vc -= 1; vs += d.vl; }
+                            vc += 1;
+                            vs += e_val[e2];
+                        }
+                    }
+                    visits[pn] = vc;
+                    vsum[pn] = vs;
+                }
+            }
         }
     }
 }
