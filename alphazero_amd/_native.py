@@ -98,6 +98,7 @@ SIGNATURES = {
     "az_lane_prepare": (_I32, [_VP, _VP]),
     "az_lane_launch": (_I32, [_VP, _I32, _VP]),
     "az_lane_finish": (_I32, [_VP, C.POINTER(AzLaneResult)]),
+    "az_streams_overlap": (_I32, [_VP, _VP, _I32, _I32, C.POINTER(_I32)]),
     "az_rng_create": (_I32, [_I32, C.POINTER(_VP)]),
     "az_rng_destroy": (_I32, [_VP]),
     "az_rng_seed": (_I32, [_VP, _I32, C.c_uint32]),

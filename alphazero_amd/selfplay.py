@@ -146,16 +146,50 @@ def sample_actions(pi: np.ndarray, u: np.ndarray) -> np.ndarray:
     return (cdf <= u[:, None]).sum(axis=1).astype(np.int32)
 
 
+# Streams for the lanes of this process, per device, each pair of them checked to run kernels at the same time
+# (az_streams_overlap): HIP maps streams onto a few hardware queues, and two lanes whose streams share a queue take turns
+# instead of overlapping. Reused by every BatchedSelfPlay of the process, so that a later driver does not land on a worse
+# pair than the first one.
+_LANE_STREAMS: dict = {}
+
+
+def lane_streams(dev, count: int, tries: int = 12):
+    """`count` streams on `dev` for the lanes of a driver: mutually overlapping ones as far as the hardware queues allow
+    (further lanes share the streams found, round-robin)."""
+    have = _LANE_STREAMS.setdefault(str(dev), [])
+    L = N.lib()
+    index = dev.index if dev.index is not None else torch.cuda.current_device()
+    for _ in range(tries):
+        if len(have) >= count:
+            break
+        cand = torch.cuda.Stream(device=dev)
+        ok = True
+        for other in have:
+            flag = C.c_int32(0)
+            N.check(L.az_streams_overlap(C.c_void_p(cand.cuda_stream), C.c_void_p(other.cuda_stream), 150, index, C.byref(flag)), "az_streams_overlap")
+            if not flag.value:
+                ok = False
+                break
+        if ok:
+            have.append(cand)
+        else:
+            _LANE_STREAMS.setdefault(str(dev) + ":shared", []).append(cand)   # kept alive: torch hands out the next stream of its pool
+    return [have[i % len(have)] for i in range(count)]
+
+
 class _Lane:
     """A share of the lockstep games with its own engine, network handle, HIP stream and random streams.
     launch() enqueues one move's search without waiting for its batches; finish() collects it, picks the
     moves and plays them. While one lane's host work runs, the other lanes' kernels keep the GPU busy."""
 
-    def __init__(self, owner, index, games, model, precision, dedup_leaves, rng_threads, own_stream):
+    def __init__(self, owner, index, games, model, precision, dedup_leaves, rng_threads, own_stream, stream=None):
         cfg = owner.cfg
         self.o, self.index, self.G = owner, index, int(games)
         self.dev = owner.dev
-        self.stream = torch.cuda.Stream(device=self.dev) if own_stream else torch.cuda.current_stream(self.dev)
+        if stream is not None:
+            self.stream = stream
+        else:
+            self.stream = torch.cuda.Stream(device=self.dev) if own_stream else torch.cuda.current_stream(self.dev)
         with torch.cuda.stream(self.stream):
             self.eng = Engine(board_size=cfg.board_size, history_len=cfg.history_len, games=self.G, komi=cfg.komi,
                               num_simulations=cfg.mcts_simulations, c_base=cfg.c_base, c_init=cfg.c_init,
@@ -516,7 +550,8 @@ class BatchedSelfPlay:
 
     def __init__(self, model, cfg: SelfPlayConfig, games: int, seed0: int = 0, dedup_leaves: bool = True,
                  precision: str = "bf16", collect_samples: bool = True, device=None, rng_threads: int = 8,
-                 lanes: int = 1, tower_workgroups: int | None = None, reuse_roots: bool = True, graph_rounds: bool | None = None):
+                 lanes: int = 1, tower_workgroups: int | None = None, reuse_roots: bool = True, graph_rounds: bool | None = None,
+                 streams=None):
         self.cfg, self.G, self.seed0 = cfg, int(games), int(seed0)
         self.graph_rounds = GRAPH_ROUNDS if graph_rounds is None else bool(graph_rounds)   # replay a move's rounds from a HIP graph
         self.reuse_roots = bool(reuse_roots)
@@ -526,7 +561,9 @@ class BatchedSelfPlay:
         self.counters = dict(moves=0, sims=0, nn_rows=0, nn_rows_nodedup=0, games=0, steps=0, depth_sum=0, graph_replays=0,
                              t_host_rng=0.0, t_host_policy=0.0, t_samples=0.0)
         share = [self.G // lanes + (1 if i < self.G % lanes else 0) for i in range(lanes)]
-        self.lanes = [_Lane(self, i, g, model, precision, dedup_leaves, rng_threads, own_stream=lanes > 1 or os.environ.get("AZ_LANE_STREAM") == "1")
+        if streams is None and lanes > 1:
+            streams = lane_streams(self.dev, lanes)
+        self.lanes = [_Lane(self, i, g, model, precision, dedup_leaves, rng_threads, own_stream=lanes > 1, stream=streams[i] if streams else None)
                       for i, g in enumerate(share)]
         # The low-latency tower variant takes the whole device per launch (one workgroup per compute unit): right for one
         # lane (256 games: 8.7 ms per move against 11.0), wrong for three or more sharing the card (768 games in 3 lanes:

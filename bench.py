@@ -536,8 +536,16 @@ def main():
     if pw.summary():
         out["power"] = pw.summary()
     if not headline and world == 1 and not a.no_side_legs:
-        # small networks: the two HIP events around every tower launch cost a visible share of a move; the same window again
-        # without them (no roofline figures from this one)
+        # small networks: the two HIP events around every tower launch cost a visible share of a move; the same moves of the
+        # same games again without them, on a fresh driver (no roofline figures from this one)
+        del sp
+        sp = BatchedSelfPlay(net, cfg, games=a.games, seed0=1 + rank * a.games, dedup_leaves=not a.no_dedup, lanes=a.lanes,
+                             tower_workgroups=twg)
+        if a.sync_search:
+            sp.set_async(False)
+        sp.begin(num_games=10 ** 9)
+        for _ in range(2 + a.warmup):          # the steps the first window ran before its clock started
+            sp.step()
         for k in sp.counters:
             sp.counters[k] = 0
         torch.cuda.synchronize()
@@ -546,7 +554,8 @@ def main():
             sp.step()
         torch.cuda.synchronize()
         dt3 = time.perf_counter() - t0
-        out["without_launch_timing"] = {"ms_per_step": round(dt3 / a.steps * 1e3, 3), "sims_per_s": round(sp.counters["sims"] / dt3, 1)}
+        out["without_launch_timing"] = {"ms_per_step": round(dt3 / a.steps * 1e3, 3), "sims_per_s": round(sp.counters["sims"] / dt3, 1),
+                                        "graph_replays": int(sp.counters.get("graph_replays", 0))}
     del sp
     if not a.no_side_legs and headline:
         # games/hour: moves/s of the timed window over the plies a finished game takes, measured on whole games of the same

@@ -308,6 +308,14 @@ int az_lane_launch(az_lane* lane, int32_t refill, void* stream);
  * an illegal sampled move (AZ_ERR_ILLEGAL, "Illegal move: (r, c)") surface here. */
 int az_lane_finish(az_lane* lane, az_lane_result* result);
 
+/* Do kernels enqueued on streams `a` and `b` run at the same time? HIP maps streams onto a few hardware queues
+ * (GPU_MAX_HW_QUEUES, 4 by default) and two streams that share one run their kernels one after the other: lanes on such a
+ * pair lose their overlap (two lanes of 256 games of a 64ch x 4 network: 2.9 instead of 1.9 ms per move). Launches a
+ * one-wave kernel that waits `microseconds` (clamped to 20..2000) on each stream and compares the wall time with one wait:
+ * *overlap = 1 when the two ran concurrently. No counterpart upstream (its self-play workers are processes,
+ * train.py:395-463); alphazero_amd/selfplay.py picks its lanes' streams with it. Synchronises both streams. */
+int az_streams_overlap(void* stream_a, void* stream_b, int32_t microseconds, int32_t device, int32_t* overlap);
+
 /* ---- replay batch assembly (go_zero/train.py:147-176 ReplayBuffer.sample, :187-207 symmetries) ----
  * Gathers `count` sampled positions idx[i] from a device-resident replay store and applies dihedral
  * symmetry sym[i] (0..7, the numbering of train.py:187-192) to planes and policy. Store layout: `bits`

@@ -143,3 +143,24 @@ def test_native_lane_and_numpy_host_half_play_the_same_games(monkeypatch):
                 assert np.array_equal(xa, xb)
     sa, sb = a.collect_samples(), b.collect_samples()
     assert len(sa[0]) == len(sb[0]) and sa[1:] == sb[1:]
+
+
+def test_lane_streams_overlap():
+    """az_streams_overlap tells a stream apart from itself (kernels on one stream run in turn) and the streams the
+    driver picks for its lanes run kernels at the same time."""
+    import torch
+    from alphazero_amd import _native as N
+    from alphazero_amd.selfplay import lane_streams
+    L = N.lib()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    s = torch.cuda.Stream()
+    flag = C.c_int32(7)
+    assert L.az_streams_overlap(C.c_void_p(s.cuda_stream), C.c_void_p(s.cuda_stream), 200, dev.index, C.byref(flag)) == 0
+    assert flag.value == 0
+    a, b = lane_streams(dev, 2)
+    assert a.cuda_stream != b.cuda_stream
+    assert L.az_streams_overlap(C.c_void_p(a.cuda_stream), C.c_void_p(b.cuda_stream), 200, dev.index, C.byref(flag)) == 0
+    assert flag.value == 1
+    assert L.az_streams_overlap(None, None, 200, dev.index, None) == N.AZ_ERR_ARG
+    many = lane_streams(dev, 9)                     # more lanes than hardware queues: the streams found are shared
+    assert len(many) == 9 and len({x.cuda_stream for x in many}) >= 2
