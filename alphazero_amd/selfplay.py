@@ -575,6 +575,15 @@ class BatchedSelfPlay:
             for ln in self.lanes:
                 if ln.net is not None and ln.net.precision == "bf16":
                     ln.net.set_device_choice(False)
+        if tower_workgroups is None and lanes > 1:
+            # Workgroups per tower launch with several lanes: the card holds two tower workgroups per compute unit, and the
+            # lanes' launches share them best when each brings one per compute unit (two lanes; a power of two below that
+            # for more, so that the eight XCDs get equal shares) and walks its boards with those: the two workgroups of a
+            # compute unit then come from different launches, in different phases of the network, instead of starting
+            # side by side (4096 games in two lanes, same box: 16.2 M simulations/s against 15.7 M with 1024 per launch;
+            # 192 per launch: 15.4 M).
+            per = max(1, 2 * cus // lanes)
+            tower_workgroups = max(cus // 2, 1 << (per.bit_length() - 1))
         if tower_workgroups is not None:
             for ln in self.lanes:
                 if ln.net is not None and ln.net.precision == "bf16":

@@ -427,7 +427,7 @@ def run_selfplay(best_model, cfg, iter_idx: int, pool=None, model_path=None, mod
     lanes = cfg.selfplay_lanes if cfg.selfplay_lanes > 0 else (2 if slots >= 256 else 1)
     sp = BatchedSelfPlay(best_model if on_gpu else _host_evaluator(best_model), SelfPlayConfig.from_train_config(cfg), games=slots,
                          seed0=selfplay_seed0(cfg, iter_idx) + first, dedup_leaves=not cfg.no_dedup_leaves, lanes=lanes,
-                         tower_workgroups=1024 if lanes > 1 else None)
+                         tower_workgroups=None)
     return sp.run(num_games=mine)
 
 

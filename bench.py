@@ -361,7 +361,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="mcts inference batch (README value 16; upstream default 8)")
     ap.add_argument("--no-dedup", action="store_true", help="evaluate repeated leaves of a batch again, as upstream does")
     ap.add_argument("--lanes", type=int, default=0, help="independent game lanes (engine + stream each) whose kernels and host work overlap (0: the configuration's)")
-    ap.add_argument("--tower-workgroups", type=int, default=0, help="workgroup limit per tower launch (0: one per CU with 1 lane, 1024 otherwise)")
+    ap.add_argument("--tower-workgroups", type=int, default=0, help="workgroup limit per tower launch (0: the driver's choice: all resident workgroups with one lane, one per CU and launch with two)")
     ap.add_argument("--sync-search", action="store_true", help="one host round trip per inference batch instead of enqueueing a move's batches back to back (A/B timing)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="search time per CPU-baseline leg")
@@ -414,7 +414,7 @@ def main():
     net = AlphaZeroNet(board_size=wl["board"], channels=wl["ch"], num_blocks=wl["blocks"]).eval().to(dev)
     cfg = SelfPlayConfig(board_size=wl["board"], mcts_simulations=wl["sims"], mcts_inference_batch=a.batch, mcts_topk_expand=wl["topk"],
                          mcts_virtual_loss=VLOSS)
-    twg = a.tower_workgroups if a.tower_workgroups > 0 else (None if a.lanes == 1 else 1024)
+    twg = a.tower_workgroups if a.tower_workgroups > 0 else None     # None: the driver's own choice for its lane count
 
     def barrier():
         if dist is not None:

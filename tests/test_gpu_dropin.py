@@ -152,7 +152,7 @@ def _small_selfplay(lanes, use_async, games=6, num_games=9, steps=None, reuse_ro
     torch.manual_seed(3)
     net = AlphaZeroNet(board_size=5, channels=32, num_blocks=2).eval().cuda()
     cfg = SelfPlayConfig(board_size=5, mcts_simulations=24, mcts_inference_batch=4, mcts_topk_expand=6)
-    sp = BatchedSelfPlay(net, cfg, games=games, seed0=11, lanes=lanes, tower_workgroups=None if lanes == 1 else 1024,
+    sp = BatchedSelfPlay(net, cfg, games=games, seed0=11, lanes=lanes, tower_workgroups=None,
                          reuse_roots=reuse_roots, graph_rounds=graph_rounds)
     assert sp.async_search
     sp.set_async(use_async)

@@ -17,7 +17,7 @@ n, ch, blocks, sims, topk, lanes = arg(5, 9), arg(6, 192), arg(7, 12), arg(8, 25
 torch.manual_seed(0)
 net = AlphaZeroNet(board_size=n, channels=ch, num_blocks=blocks).eval().to("cuda:0")
 cfg = SelfPlayConfig(board_size=n, mcts_simulations=sims, mcts_inference_batch=B, mcts_topk_expand=topk)
-sp = BatchedSelfPlay(net, cfg, games=G, seed0=1, dedup_leaves=dedup, lanes=lanes, tower_workgroups=1024 if lanes > 1 else None)
+sp = BatchedSelfPlay(net, cfg, games=G, seed0=1, dedup_leaves=dedup, lanes=lanes, tower_workgroups=None)
 sp.begin(num_games=10 ** 9)
 for _ in range(2):
     sp.step()

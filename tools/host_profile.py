@@ -10,7 +10,7 @@ G, steps, lanes, ch, blocks, sims = arg(1, 512), arg(2, 30), arg(3, 4), arg(4, 6
 torch.manual_seed(0)
 net = AlphaZeroNet(board_size=9, channels=ch, num_blocks=blocks).eval().to("cuda:0")
 cfg = SelfPlayConfig(board_size=9, mcts_simulations=sims, mcts_inference_batch=16, mcts_topk_expand=48)
-sp = BatchedSelfPlay(net, cfg, games=G, seed0=1, lanes=lanes, tower_workgroups=1024 if lanes > 1 else None)
+sp = BatchedSelfPlay(net, cfg, games=G, seed0=1, lanes=lanes, tower_workgroups=None)
 sp.begin(num_games=10 ** 9)
 for _ in range(3):
     sp.step()

@@ -15,7 +15,7 @@ graph = "graph" in sys.argv[7:]
 torch.manual_seed(0)
 net = AlphaZeroNet(board_size=9, channels=ch, num_blocks=blocks).eval().cuda()
 cfg = SelfPlayConfig(board_size=9, mcts_simulations=sims, mcts_inference_batch=16, mcts_topk_expand=topk)
-sp = BatchedSelfPlay(net, cfg, games=games, seed0=1, lanes=lanes, graph_rounds=graph, tower_workgroups=None if lanes == 1 else 1024)
+sp = BatchedSelfPlay(net, cfg, games=games, seed0=1, lanes=lanes, graph_rounds=graph, tower_workgroups=None)
 sp.begin(num_games=10 ** 9)
 for _ in range(6):
     sp.step()
