@@ -575,15 +575,14 @@ class BatchedSelfPlay:
             for ln in self.lanes:
                 if ln.net is not None and ln.net.precision == "bf16":
                     ln.net.set_device_choice(False)
-        if tower_workgroups is None and lanes > 1:
-            # Workgroups per tower launch with several lanes: the card holds two tower workgroups per compute unit, and the
-            # lanes' launches share them best when each brings one per compute unit (two lanes; a power of two below that
-            # for more, so that the eight XCDs get equal shares) and walks its boards with those: the two workgroups of a
-            # compute unit then come from different launches, in different phases of the network, instead of starting
-            # side by side (4096 games in two lanes, same box: 16.2 M simulations/s against 15.7 M with 1024 per launch;
-            # 192 per launch: 15.4 M).
-            per = max(1, 2 * cus // lanes)
-            tower_workgroups = max(cus // 2, 1 << (per.bit_length() - 1))
+        if tower_workgroups is None and lanes > 2:
+            # Workgroups per tower launch. One or two lanes: the library's default (as many as the card holds at once, each
+            # walking its share of the boards; for the two-per-CU kernels that is two per compute unit). More, shorter-lived
+            # workgroups per launch (1024, the setting while four lanes were the default) let the lanes' launches interleave at
+            # a finer grain and cost more than that gains: 4096 games in two lanes, same box, 16.2 M simulations/s with the
+            # default against 15.5 M with 1024 and 15.4 M with 192 (a count the eight XCDs do not share evenly). Three or more
+            # lanes: half the default, so that two launches fit side by side (four lanes: 16.0 M against 15.4 M).
+            tower_workgroups = max(1, cus // 2)
         if tower_workgroups is not None:
             for ln in self.lanes:
                 if ln.net is not None and ln.net.precision == "bf16":
