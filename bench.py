@@ -60,7 +60,7 @@ def tower_flops_per_position(n=9, cin=21, ch=CH, blocks=BLOCKS):
 def tower_traffic_per_launch(rows_per_launch):
     """HBM-side bytes per tower launch from the committed PMC summary (separate FETCH_SIZE / WRITE_SIZE passes of
     this benchmark, collected offline: counters cannot be read from inside the run), scaled by rows."""
-    for name in ("r03d_tower_hbm_traffic.json", "r02_tower_hbm_traffic.json", "r01h_tower_hbm_traffic.json"):
+    for name in ("r03f_tower_hbm_traffic.json", "r02_tower_hbm_traffic.json", "r01h_tower_hbm_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 d = json.load(f)

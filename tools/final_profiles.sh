@@ -1,7 +1,7 @@
 #!/bin/sh
 # The measurement set behind the figures of a round's final tree: sh tools/final_profiles.sh <tag> <part>   (GPU box, repo root)
 #   part a: rocprofv3 passes of the headline (tools/profile_run.sh), the default bench line, the 330-step window, one lane
-#   part b: the other BASELINE configurations, few-game moves, one search, search kernels over whole games (old build optional)
+#   part b: the other BASELINE configurations, few-game moves, one search, kernel stats of configs[1] in one lane
 tag=${1:-final}; part=${2:-a}
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=/root/repo
 O=$R/gpurun_out; mkdir -p $O
@@ -36,12 +36,13 @@ else
     rm -rf /tmp/fpk
     timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/fpk -- python3 $R/bench.py --config 2 --games $g --lanes 1 --no-cpu-baseline --no-side-legs --steps 20 --warmup 3 > /dev/null 2>/tmp/fpk.err || { tail -5 /tmp/fpk.err; exit 1; }
     cp $(find /tmp/fpk -name "*kernel_stats.csv" | head -n 1) $O/${tag}_config2_${g}games_1lane_kernel_stats.csv
-    grep -E "k_expand_select|k_leaf|k_select|k_tails|k_move_tail" $O/${tag}_config2_${g}games_1lane_kernel_stats.csv | awk -F'","' -v g=$g '{n=$1; sub(/\(.*/,"",n); printf "%d games: %s avg %.1f us\n", g, n, $4/1000}'
+    python3 - $O/${tag}_config2_${g}games_1lane_kernel_stats.csv $g <<'PY'
+import csv, sys
+for r in csv.DictReader(open(sys.argv[1])):
+    n = r["Name"].split("(")[0]
+    if any(k in n for k in ("k_expand_select", "k_leaf", "k_select", "k_tails", "k_move_tail", "k_tower")):
+        print(sys.argv[2], "games:", n[:64], "avg %.1f us" % (float(r["AverageNs"]) / 1e3))
+PY
   done
-  libs=main; [ -f $R/alphazero_amd/libazamd_old.so ] && libs="old main"
-  ( echo "# search kernels over whole games (moves 6-126 of 512 games of 9x9 64ch x 4, one lane), rocprofv3 kernel stats on one box;"
-    echo "# libazamd_old.so: the tree before the register-held levels, libazamd.so: this tree (tools/ab_lib_kstats.sh)"
-    sh $R/tools/ab_lib_kstats.sh old ) > $O/${tag}_search_kernels_whole_games.txt 2>&1 || exit 1
-  grep -E "==|k_expand_select|k_leaf" $O/${tag}_search_kernels_whole_games.txt
 fi
 echo final_profiles $part done
