@@ -2,6 +2,7 @@
 
   python tools/profile_summary.py trace  <kernel_trace.csv>            mean launch duration and merged busy time
   python tools/profile_summary.py pmc    <fetch_counter_collection.csv> <write_counter_collection.csv>
+  python tools/profile_summary.py pmc_search <fetch_counter_collection.csv> <write_counter_collection.csv>   the search / rules / tail kernels
 
 `trace`: launches of different lanes overlap on the GPU, so next to the plain mean of (end - start) the
 length of the union of the launch intervals divided by the launch count is printed; bench.py computes the
@@ -46,5 +47,15 @@ def pmc(fetch_path, write_path, key="k_tower"):
 if __name__ == "__main__":
     if sys.argv[1] == "trace":
         print(json.dumps(trace(sys.argv[2]), indent=1))
+    elif sys.argv[1] == "pmc_search":
+        out = {}
+        for key in ("k_expand_select", "k_select", "k_leaf", "k_expand_backup", "k_expand_root", "k_move_tail", "k_tails"):
+            try:
+                d = pmc(sys.argv[2], sys.argv[3], key="::" + key)
+                out[key] = {"launches": d["FETCH_SIZE"]["all"]["dispatches"], "fetch_bytes_per_launch": d["FETCH_SIZE"]["all"]["avg_bytes"],
+                            "write_bytes_per_launch": d["WRITE_SIZE"]["all"]["avg_bytes"], "bytes_per_launch": d["bytes_per_launch"]}
+            except (ZeroDivisionError, KeyError):
+                continue
+        print(json.dumps(out, indent=1))
     else:
         print(json.dumps(pmc(sys.argv[2], sys.argv[3]), indent=1))
