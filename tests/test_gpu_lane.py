@@ -117,13 +117,20 @@ def test_one_move_equals_the_step_by_step_search_and_upstream_move_choice():
     ref.close()
 
 
-def test_native_lane_and_numpy_host_half_play_the_same_games(monkeypatch):
+@pytest.mark.parametrize("kw", [dict(), dict(temp_moves=2, temp_mid_moves=5, temp_mid=0.4, temp_end=0.05),
+                                dict(temp_moves=1, temp_mid_moves=2, temp_end=1e-3, resign_threshold=0.02),
+                                dict(temp_start=1e-3, dirichlet_eps=0.0, resign_threshold=0.3, mcts_virtual_loss=0.0),
+                                dict(opening_book_prob=1.0, opening_book_max_moves=3)],
+                         ids=["defaults", "three_temperatures", "argmax_and_resign", "no_noise_no_virtual_loss", "opening_book"])
+def test_native_lane_and_numpy_host_half_play_the_same_games(monkeypatch, kw):
+    """Temperature phases (sampled and arg-max moves, mcts.py:265-283), resignation (train.py:333-337), searches without
+    noise or virtual loss, book openings: the move's tail on the device against the NumPy host half."""
     import torch
     from alphazero_amd import selfplay
     from alphazero_amd.model import AlphaZeroNet
     torch.manual_seed(3)
     net = AlphaZeroNet(board_size=5, channels=32, num_blocks=2).eval().cuda()
-    cfg = selfplay.SelfPlayConfig(board_size=5, mcts_simulations=24, mcts_inference_batch=4, mcts_topk_expand=6)
+    cfg = selfplay.SelfPlayConfig(board_size=5, mcts_simulations=24, mcts_inference_batch=4, mcts_topk_expand=6, **kw)
     runs = []
     for native in (True, False):
         monkeypatch.setattr(selfplay, "NATIVE_LANE", native)
